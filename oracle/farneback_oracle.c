@@ -1,0 +1,544 @@
+/*
+ * oracle/farneback_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Scalar CPU restatement of the per-frame-pair motion path of Funscript-Flow:
+ *
+ *   cv2.calcOpticalFlowFarneback(p0, p1, None, 0.5, 3, 15, 3, 5, 1.2, 0)   FunscriptFlow.pyw:878-879
+ *   max_divergence(flow)                                                   FunscriptFlow.pyw:748-758
+ *   cv2.cartToPolar + np.mean  (cut statistic)                             FunscriptFlow.pyw:889-894
+ *   radial_motion_weighted(flow, center, is_cut, pov_mode)                 FunscriptFlow.pyw:761-785
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this
+ * library; the product (funscript_flow_amd/) never does.
+ *
+ * PARITY STATUS
+ *   - max_divergence / radial_motion_weighted / centre smoothing: pinned by golden vectors
+ *     generated from the real reference functions (oracle/gen_golden.py, tests/golden/).
+ *   - Farneback arithmetic: lives in a third-party dependency that is NOT in /root/reference
+ *     (opencv-python == 4.11.0.86, uv.lock:238-239) and is not installed here, and the reference
+ *     holds no test or fixture for it => **parity unpinned** against cv2.  What follows restates
+ *     the published algorithm (OpenCV 4.x modules/video/src/optflowgf.cpp: FarnebackPrepareGaussian,
+ *     FarnebackPolyExp, FarnebackUpdateMatrices, FarnebackUpdateFlow_Blur,
+ *     FarnebackOpticalFlowImpl::calc; imgproc GaussianBlur / getGaussianKernel / resize INTER_LINEAR)
+ *     as specified in SURVEY.md Appendix A, and is pinned only by analytic known answers
+ *     (tests/test_oracle_farneback.py).
+ *
+ * Arithmetic conventions (these DEFINE the oracle; the HIP kernels follow them op for op):
+ *   - compile with -ffp-contract=off: no FMA contraction anywhere;
+ *   - float where OpenCV uses float, double where it uses double (PolyExp horizontal
+ *     accumulators, box sums, 2x2 solve);
+ *   - the 15x15 box sum is the exact-window sum accumulated in double in the fixed order
+ *     rows y-7..y+7 then columns x-7..x+7 (REPLICATE border).  OpenCV reaches the same sums with
+ *     running (sliding) sums; the two differ only in double rounding (~1e-16 relative);
+ *   - the separable Gaussian uses the symmetric form k0*c + sum_j kj*(x[-j]+x[+j]) in float,
+ *     horizontal pass first, BORDER_REFLECT_101;
+ *   - bilinear resize follows OpenCV's coordinate rule for every scale (the exact-2x INTER_AREA
+ *     shortcut of OpenCV computes the same 2x2 mean up to 1 ulp and is not reproduced).
+ *
+ * Layouts: images row-major; R and M are 5 PLANES of h*w floats (plane c at base + c*h*w);
+ * flow is interleaved (h, w, 2) float exactly as cv2 returns it.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+#define POLY_N 5
+#define POLY_SIGMA 1.2
+#define WINSIZE 15
+#define NUM_ITERS 3
+#define PYR_LEVELS 3
+#define PYR_SCALE 0.5
+#define MIN_SIZE 32
+
+static inline int cv_round(double v) { return (int)lrint(v); } /* round-half-even */
+static inline int cv_floorf(float v) { return (int)floorf(v); }
+static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static inline int reflect101(int p, int n) {
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) {
+        if (p < 0) p = -p;
+        else p = 2 * (n - 1) - p;
+    }
+    return p;
+}
+
+/* ---- A.1 level logic (FarnebackOpticalFlowImpl::calc) ------------------------------- */
+ORC_API int orc_num_levels(int w, int h) {
+    int k;
+    double scale = 1.0;
+    for (k = 0; k < PYR_LEVELS; k++) {
+        scale *= PYR_SCALE;
+        if (w * scale < MIN_SIZE || h * scale < MIN_SIZE) break;
+    }
+    return k;
+}
+
+ORC_API void orc_level_params(int w, int h, int k, int *lw, int *lh, double *sigma, int *ksize) {
+    double scale = 1.0;
+    for (int i = 0; i < k; i++) scale *= PYR_SCALE;
+    double s = (1.0 / scale - 1.0) * 0.5;
+    int sm = cv_round(s * 5) | 1;
+    if (sm < 3) sm = 3;
+    *lw = cv_round(w * scale);
+    *lh = cv_round(h * scale);
+    *sigma = s;
+    *ksize = sm;
+}
+
+/* ---- A.2 getGaussianKernel(n, sigma) as CV_32F -------------------------------------- */
+ORC_API void orc_gaussian_kernel(int n, double sigma, float *out) {
+    static const float tab1[] = {1.f};
+    static const float tab3[] = {0.25f, 0.5f, 0.25f};
+    static const float tab5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    static const float tab7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    const float *fixed = 0;
+    if (sigma <= 0 && (n & 1) && n <= 7) fixed = n == 1 ? tab1 : n == 3 ? tab3 : n == 5 ? tab5 : tab7;
+    double sg = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double scale2x = -0.5 / (sg * sg);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        double t = fixed ? (double)fixed[i] : exp(scale2x * x * x);
+        out[i] = (float)t;
+        sum += out[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < n; i++) out[i] = (float)(out[i] * sum);
+}
+
+/* ---- bilinear resize tables (imgproc resize INTER_LINEAR, float) --------------------- */
+ORC_API void orc_resize_table(int src, int dst, int *i0, int *i1, float *f) {
+    double scale = (double)src / dst;
+    for (int d = 0; d < dst; d++) {
+        float fx = (float)((d + 0.5) * scale - 0.5);
+        int sx = cv_floorf(fx);
+        fx -= sx;
+        if (sx < 0) { sx = 0; fx = 0.f; }
+        if (sx >= src - 1) { sx = src - 1; fx = 0.f; }
+        i0[d] = sx;
+        i1[d] = sx + 1 < src ? sx + 1 : src - 1;
+        f[d] = fx;
+    }
+}
+
+/* ---- BGR -> gray, 8-bit fixed point (cvtColor COLOR_BGR2GRAY, 15-bit coefficients) ---- */
+ORC_API void orc_bgr2gray(const uint8_t *bgr, int w, int h, int stride, uint8_t *gray) {
+    for (int y = 0; y < h; y++) {
+        const uint8_t *s = bgr + (size_t)y * stride;
+        for (int x = 0; x < w; x++) {
+            int b = s[x * 3], g = s[x * 3 + 1], r = s[x * 3 + 2];
+            gray[(size_t)y * w + x] = (uint8_t)((b * 3735 + g * 19235 + r * 9798 + 16384) >> 15);
+        }
+    }
+}
+
+/* ---- per-level image: float(img) -> GaussianBlur(full res) -> resize ------------------ */
+ORC_API void orc_pyr_level(const uint8_t *img, int w, int h, int stride, int k, float *I) {
+    int lw, lh, ks;
+    double sigma;
+    orc_level_params(w, h, k, &lw, &lh, &sigma, &ks);
+    int r = ks / 2;
+    float kern[64];
+    orc_gaussian_kernel(ks, sigma, kern);
+
+    float *tmp = (float *)malloc(sizeof(float) * (size_t)w * h);
+    float *blur = (float *)malloc(sizeof(float) * (size_t)w * h);
+    /* horizontal pass */
+    for (int y = 0; y < h; y++) {
+        const uint8_t *s = img + (size_t)y * stride;
+        for (int x = 0; x < w; x++) {
+            float acc = kern[r] * (float)s[x];
+            for (int j = 1; j <= r; j++) {
+                float a = (float)s[reflect101(x - j, w)];
+                float b = (float)s[reflect101(x + j, w)];
+                acc = acc + kern[r + j] * (a + b);
+            }
+            tmp[(size_t)y * w + x] = acc;
+        }
+    }
+    /* vertical pass */
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            float acc = kern[r] * tmp[(size_t)y * w + x];
+            for (int j = 1; j <= r; j++) {
+                float a = tmp[(size_t)reflect101(y - j, h) * w + x];
+                float b = tmp[(size_t)reflect101(y + j, h) * w + x];
+                acc = acc + kern[r + j] * (a + b);
+            }
+            blur[(size_t)y * w + x] = acc;
+        }
+    /* bilinear resize */
+    int *x0 = (int *)malloc(sizeof(int) * lw), *x1 = (int *)malloc(sizeof(int) * lw);
+    int *y0 = (int *)malloc(sizeof(int) * lh), *y1 = (int *)malloc(sizeof(int) * lh);
+    float *fx = (float *)malloc(sizeof(float) * lw), *fy = (float *)malloc(sizeof(float) * lh);
+    orc_resize_table(w, lw, x0, x1, fx);
+    orc_resize_table(h, lh, y0, y1, fy);
+    for (int y = 0; y < lh; y++) {
+        const float *r0 = blur + (size_t)y0[y] * w, *r1 = blur + (size_t)y1[y] * w;
+        float b1 = fy[y], b0 = 1.f - b1;
+        for (int x = 0; x < lw; x++) {
+            float a1 = fx[x], a0 = 1.f - a1;
+            float t0 = r0[x0[x]] * a0 + r0[x1[x]] * a1;
+            float t1 = r1[x0[x]] * a0 + r1[x1[x]] * a1;
+            I[(size_t)y * lw + x] = t0 * b0 + t1 * b1;
+        }
+    }
+    free(tmp); free(blur); free(x0); free(x1); free(y0); free(y1); free(fx); free(fy);
+}
+
+/* ---- A.3 FarnebackPrepareGaussian ---------------------------------------------------- */
+/* g, xg, xxg: arrays of n+1 floats (index 0..n); ig: {ig11, ig03, ig33, ig55} */
+ORC_API void orc_polyexp_prepare(float *g, float *xg, float *xxg, double *ig) {
+    const int n = POLY_N;
+    float gg[2 * POLY_N + 1];
+    double s = 0;
+    for (int x = -n; x <= n; x++) {
+        gg[x + n] = (float)exp(-x * x / (2 * POLY_SIGMA * POLY_SIGMA));
+        s += gg[x + n];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) gg[x + n] = (float)(gg[x + n] * s);
+    for (int x = 0; x <= n; x++) {
+        g[x] = gg[x + n];
+        xg[x] = (float)(x * gg[x + n]);
+        xxg[x] = (float)(x * x * gg[x + n]);
+    }
+    double G[6][6];
+    memset(G, 0, sizeof(G));
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            float p = gg[y + n] * gg[x + n];
+            G[0][0] += p;
+            G[1][1] += p * x * x;
+            G[3][3] += p * x * x * x * x;
+            G[5][5] += p * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    /* invert the 6x6 SPD matrix by Gauss-Jordan in double */
+    double A[6][12];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 12; j++) A[i][j] = j < 6 ? G[i][j] : (j - 6 == i ? 1.0 : 0.0);
+    for (int c = 0; c < 6; c++) {
+        int p = c;
+        for (int r = c + 1; r < 6; r++)
+            if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+        if (p != c)
+            for (int j = 0; j < 12; j++) { double t = A[c][j]; A[c][j] = A[p][j]; A[p][j] = t; }
+        double d = 1.0 / A[c][c];
+        for (int j = 0; j < 12; j++) A[c][j] *= d;
+        for (int r = 0; r < 6; r++)
+            if (r != c) {
+                double f = A[r][c];
+                if (f != 0)
+                    for (int j = 0; j < 12; j++) A[r][j] -= f * A[c][j];
+            }
+    }
+    ig[0] = A[1][7];  /* invG(1,1) */
+    ig[1] = A[0][9];  /* invG(0,3) */
+    ig[2] = A[3][9];  /* invG(3,3) */
+    ig[3] = A[5][11]; /* invG(5,5) */
+}
+
+/* ---- A.3 FarnebackPolyExp: I (h,w) -> R 5 planes -------------------------------------- */
+ORC_API void orc_polyexp(const float *I, int w, int h, float *R) {
+    const int n = POLY_N;
+    float g[POLY_N + 1], xg[POLY_N + 1], xxg[POLY_N + 1];
+    double ig[4];
+    orc_polyexp_prepare(g, xg, xxg, ig);
+    const double ig11 = ig[0], ig03 = ig[1], ig33 = ig[2], ig55 = ig[3];
+    size_t plane = (size_t)w * h;
+    float *row = (float *)malloc(sizeof(float) * 3 * (size_t)w);
+    for (int y = 0; y < h; y++) {
+        const float *s0 = I + (size_t)y * w;
+        /* vertical part, float, rows clamped */
+        for (int x = 0; x < w; x++) {
+            row[x * 3] = s0[x] * g[0];
+            row[x * 3 + 1] = row[x * 3 + 2] = 0.f;
+        }
+        for (int k = 1; k <= n; k++) {
+            const float *a = I + (size_t)(y - k < 0 ? 0 : y - k) * w;
+            const float *b = I + (size_t)(y + k > h - 1 ? h - 1 : y + k) * w;
+            for (int x = 0; x < w; x++) {
+                float p = a[x] + b[x];
+                float t0 = row[x * 3] + g[k] * p;
+                float t1 = row[x * 3 + 1] + xg[k] * (b[x] - a[x]);
+                float t2 = row[x * 3 + 2] + xxg[k] * p;
+                row[x * 3] = t0;
+                row[x * 3 + 1] = t1;
+                row[x * 3 + 2] = t2;
+            }
+        }
+        /* horizontal part, double accumulators, columns clamped (replicated triples) */
+        for (int x = 0; x < w; x++) {
+            float g0 = g[0];
+            double b1 = row[x * 3] * g0, b2 = 0, b3 = row[x * 3 + 1] * g0, b4 = 0,
+                   b5 = row[x * 3 + 2] * g0, b6 = 0;
+            for (int k = 1; k <= n; k++) {
+                int p = x + k > w - 1 ? w - 1 : x + k;
+                int m = x - k < 0 ? 0 : x - k;
+                double tg = row[p * 3] + row[m * 3]; /* float add, widened */
+                g0 = g[k];
+                b1 += tg * g0;
+                b4 += tg * xxg[k];
+                b2 += (row[p * 3] - row[m * 3]) * xg[k];         /* float product */
+                b3 += (row[p * 3 + 1] + row[m * 3 + 1]) * g0;     /* float product */
+                b6 += (row[p * 3 + 1] - row[m * 3 + 1]) * xg[k];  /* float product */
+                b5 += (row[p * 3 + 2] + row[m * 3 + 2]) * g0;     /* float product */
+            }
+            size_t o = (size_t)y * w + x;
+            R[0 * plane + o] = (float)(b3 * ig11);
+            R[1 * plane + o] = (float)(b2 * ig11);
+            R[2 * plane + o] = (float)(b1 * ig03 + b5 * ig33);
+            R[3 * plane + o] = (float)(b1 * ig03 + b4 * ig33);
+            R[4 * plane + o] = (float)(b6 * ig55);
+        }
+    }
+    free(row);
+}
+
+/* ---- flow upsample between levels: resize(prevFlow, (w,h), INTER_LINEAR) * (1/pyrScale) */
+ORC_API void orc_flow_upsample(const float *prev, int pw, int ph, float *flow, int w, int h) {
+    int *x0 = (int *)malloc(sizeof(int) * w), *x1 = (int *)malloc(sizeof(int) * w);
+    int *y0 = (int *)malloc(sizeof(int) * h), *y1 = (int *)malloc(sizeof(int) * h);
+    float *fx = (float *)malloc(sizeof(float) * w), *fy = (float *)malloc(sizeof(float) * h);
+    orc_resize_table(pw, w, x0, x1, fx);
+    orc_resize_table(ph, h, y0, y1, fy);
+    const float mul = (float)(1.0 / PYR_SCALE);
+    for (int y = 0; y < h; y++) {
+        const float *r0 = prev + (size_t)y0[y] * pw * 2, *r1 = prev + (size_t)y1[y] * pw * 2;
+        float b1 = fy[y], b0 = 1.f - b1;
+        for (int x = 0; x < w; x++) {
+            float a1 = fx[x], a0 = 1.f - a1;
+            for (int c = 0; c < 2; c++) {
+                float t0 = r0[x0[x] * 2 + c] * a0 + r0[x1[x] * 2 + c] * a1;
+                float t1 = r1[x0[x] * 2 + c] * a0 + r1[x1[x] * 2 + c] * a1;
+                flow[((size_t)y * w + x) * 2 + c] = (t0 * b0 + t1 * b1) * mul;
+            }
+        }
+    }
+    free(x0); free(x1); free(y0); free(y1); free(fx); free(fy);
+}
+
+/* ---- A.4 FarnebackUpdateMatrices ------------------------------------------------------ */
+ORC_API void orc_update_matrices(const float *R0, const float *R1, const float *flow, int w, int h,
+                                 float *M) {
+    static const float border[5] = {0.14f, 0.14f, 0.4472f, 0.4472f, 0.4472f};
+    const int BORDER = 5;
+    size_t pl = (size_t)w * h;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t o = (size_t)y * w + x;
+            float dx = flow[o * 2], dy = flow[o * 2 + 1];
+            float fx = x + dx, fy = y + dy;
+            int x1 = cv_floorf(fx), y1 = cv_floorf(fy);
+            float r2, r3, r4, r5, r6;
+            fx -= x1;
+            fy -= y1;
+            if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+                float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy,
+                      a11 = fx * fy;
+                size_t p = (size_t)y1 * w + x1;
+#define BIL(c) (a00 * R1[(c)*pl + p] + a01 * R1[(c)*pl + p + 1] + a10 * R1[(c)*pl + p + w] + a11 * R1[(c)*pl + p + w + 1])
+                r2 = BIL(0);
+                r3 = BIL(1);
+                r4 = BIL(2);
+                r5 = BIL(3);
+                r6 = BIL(4);
+#undef BIL
+                r4 = (R0[2 * pl + o] + r4) * 0.5f;
+                r5 = (R0[3 * pl + o] + r5) * 0.5f;
+                r6 = (R0[4 * pl + o] + r6) * 0.25f;
+            } else {
+                r2 = r3 = 0.f;
+                r4 = R0[2 * pl + o];
+                r5 = R0[3 * pl + o];
+                r6 = R0[4 * pl + o] * 0.5f;
+            }
+            r2 = (R0[0 * pl + o] - r2) * 0.5f;
+            r3 = (R0[1 * pl + o] - r3) * 0.5f;
+            r2 += r4 * dy + r6 * dx;
+            r3 += r6 * dy + r5 * dx;
+            if ((unsigned)(x - BORDER) >= (unsigned)(w - BORDER * 2) ||
+                (unsigned)(y - BORDER) >= (unsigned)(h - BORDER * 2)) {
+                float scale = (x < BORDER ? border[x] : 1.f) * (x >= w - BORDER ? border[w - x - 1] : 1.f) *
+                              (y < BORDER ? border[y] : 1.f) * (y >= h - BORDER ? border[h - y - 1] : 1.f);
+                r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+            }
+            M[0 * pl + o] = r4 * r4 + r6 * r6;
+            M[1 * pl + o] = (r4 + r5) * r6;
+            M[2 * pl + o] = r5 * r5 + r6 * r6;
+            M[3 * pl + o] = r4 * r2 + r6 * r3;
+            M[4 * pl + o] = r6 * r2 + r5 * r3;
+        }
+}
+
+/* ---- A.5 FarnebackUpdateFlow_Blur: 15x15 box (double) + 2x2 solve --------------------- */
+ORC_API void orc_blur_solve(const float *M, int w, int h, float *flow) {
+    const int m = WINSIZE / 2;
+    const double scale = 1. / (WINSIZE * WINSIZE);
+    size_t pl = (size_t)w * h;
+    double *vs = (double *)malloc(sizeof(double) * 5 * (size_t)w);
+    for (int y = 0; y < h; y++) {
+        for (int c = 0; c < 5; c++)
+            for (int x = 0; x < w; x++) {
+                double s = 0;
+                for (int j = -m; j <= m; j++) s += (double)M[c * pl + (size_t)clampi(y + j, 0, h - 1) * w + x];
+                vs[c * (size_t)w + x] = s;
+            }
+        for (int x = 0; x < w; x++) {
+            double b[5];
+            for (int c = 0; c < 5; c++) {
+                double s = 0;
+                for (int i = -m; i <= m; i++) s += vs[c * (size_t)w + clampi(x + i, 0, w - 1)];
+                b[c] = s;
+            }
+            double g11 = b[0] * scale, g12 = b[1] * scale, g22 = b[2] * scale, h1 = b[3] * scale,
+                   h2 = b[4] * scale;
+            double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            flow[((size_t)y * w + x) * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+            flow[((size_t)y * w + x) * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+    }
+    free(vs);
+}
+
+/* ---- A.1 driver ------------------------------------------------------------------------ */
+/* Optional dumps: when dump_level == k (>=0) the level-k intermediates are copied out after
+ * `dump_iter` blur iterations (0 => just after the initial UpdateMatrices):
+ *   dI0/dI1 (lh*lw), dR0/dR1 (5*lh*lw), dM (5*lh*lw), dflow (lh*lw*2). NULL pointers are skipped. */
+ORC_API int orc_farneback_dbg(const uint8_t *prev, const uint8_t *next, int w, int h, int stride, float *flow_out,
+                              int dump_level, int dump_iter, float *dI0, float *dI1, float *dR0, float *dR1,
+                              float *dM, float *dflow) {
+    int levels = orc_num_levels(w, h);
+    size_t N = (size_t)w * h;
+    float *I = (float *)malloc(sizeof(float) * N);
+    float *R0 = (float *)malloc(sizeof(float) * 5 * N), *R1 = (float *)malloc(sizeof(float) * 5 * N);
+    float *M = (float *)malloc(sizeof(float) * 5 * N);
+    float *flow = (float *)malloc(sizeof(float) * 2 * N), *prevflow = (float *)malloc(sizeof(float) * 2 * N);
+    if (!I || !R0 || !R1 || !M || !flow || !prevflow) return -1;
+    int pw = 0, ph = 0;
+    for (int k = levels; k >= 0; k--) {
+        int lw, lh, ks;
+        double sigma;
+        orc_level_params(w, h, k, &lw, &lh, &sigma, &ks);
+        size_t n = (size_t)lw * lh;
+        if (pw == 0) memset(flow, 0, sizeof(float) * 2 * n);
+        else orc_flow_upsample(prevflow, pw, ph, flow, lw, lh);
+        orc_pyr_level(prev, w, h, stride, k, I);
+        if (k == dump_level && dI0) memcpy(dI0, I, sizeof(float) * n);
+        orc_polyexp(I, lw, lh, R0);
+        orc_pyr_level(next, w, h, stride, k, I);
+        if (k == dump_level && dI1) memcpy(dI1, I, sizeof(float) * n);
+        orc_polyexp(I, lw, lh, R1);
+        if (k == dump_level && dR0) memcpy(dR0, R0, sizeof(float) * 5 * n);
+        if (k == dump_level && dR1) memcpy(dR1, R1, sizeof(float) * 5 * n);
+        orc_update_matrices(R0, R1, flow, lw, lh, M);
+        int dumped = 0;
+        for (int it = 0; it < NUM_ITERS; it++) {
+            if (k == dump_level && it == dump_iter) {
+                if (dM) memcpy(dM, M, sizeof(float) * 5 * n);
+                if (dflow) memcpy(dflow, flow, sizeof(float) * 2 * n);
+                dumped = 1;
+            }
+            orc_blur_solve(M, lw, lh, flow);
+            if (it < NUM_ITERS - 1) orc_update_matrices(R0, R1, flow, lw, lh, M);
+        }
+        if (k == dump_level && !dumped) {
+            if (dM) memcpy(dM, M, sizeof(float) * 5 * n);
+            if (dflow) memcpy(dflow, flow, sizeof(float) * 2 * n);
+        }
+        memcpy(prevflow, flow, sizeof(float) * 2 * n);
+        pw = lw;
+        ph = lh;
+    }
+    memcpy(flow_out, flow, sizeof(float) * 2 * N);
+    free(I); free(R0); free(R1); free(M); free(flow); free(prevflow);
+    return 0;
+}
+
+ORC_API int orc_farneback(const uint8_t *prev, const uint8_t *next, int w, int h, int stride, float *flow_out) {
+    return orc_farneback_dbg(prev, next, w, h, stride, flow_out, -1, 0, 0, 0, 0, 0, 0, 0);
+}
+
+/* ---- B.1 max_divergence (FunscriptFlow.pyw:748-758) ------------------------------------ */
+/* div = np.gradient(u, axis=0) + np.gradient(v, axis=1); first argmax of |div| in C order. */
+static inline float grad1(float lo, float mid, float hi, int idx, int n) {
+    (void)mid;
+    if (n < 2) return 0.f;
+    if (idx == 0 || idx == n - 1) return hi - lo; /* caller passes the one-sided pair */
+    return (hi - lo) / 2.0f;
+}
+
+ORC_API void orc_divergence(const float *flow, int w, int h, float *div) {
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int ya = y == 0 ? 0 : y - 1, yb = y == h - 1 ? h - 1 : y + 1;
+            int xa = x == 0 ? 0 : x - 1, xb = x == w - 1 ? w - 1 : x + 1;
+            float du = grad1(flow[((size_t)ya * w + x) * 2], 0.f, flow[((size_t)yb * w + x) * 2], y, h);
+            float dv = grad1(flow[((size_t)y * w + xa) * 2 + 1], 0.f, flow[((size_t)y * w + xb) * 2 + 1], x, w);
+            div[(size_t)y * w + x] = du + dv;
+        }
+}
+
+ORC_API void orc_max_divergence(const float *flow, int w, int h, int *ox, int *oy, float *oval) {
+    float best = -1.f, bval = 0.f;
+    size_t bidx = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            int ya = y == 0 ? 0 : y - 1, yb = y == h - 1 ? h - 1 : y + 1;
+            int xa = x == 0 ? 0 : x - 1, xb = x == w - 1 ? w - 1 : x + 1;
+            float du = grad1(flow[((size_t)ya * w + x) * 2], 0.f, flow[((size_t)yb * w + x) * 2], y, h);
+            float dv = grad1(flow[((size_t)y * w + xa) * 2 + 1], 0.f, flow[((size_t)y * w + xb) * 2 + 1], x, w);
+            float d = du + dv;
+            float a = fabsf(d);
+            if (a > best) { best = a; bval = d; bidx = (size_t)y * w + x; }
+        }
+    *ox = (int)(bidx % w);
+    *oy = (int)(bidx / w);
+    *oval = bval;
+}
+
+/* ---- B.3 cut statistic (FunscriptFlow.pyw:889-890): mean of sqrt(u^2+v^2) -------------- */
+/* The magnitudes are float (cv2.cartToPolar); the mean is returned in double so that callers can
+ * compare against np.mean's float32 pairwise result with a stated tolerance. */
+ORC_API double orc_mean_mag(const float *flow, int w, int h) {
+    double s = 0;
+    for (size_t i = 0; i < (size_t)w * h; i++) {
+        float u = flow[i * 2], v = flow[i * 2 + 1];
+        s += (double)sqrtf(u * u + v * v);
+    }
+    return s / ((double)w * h);
+}
+
+/* ---- B.2 radial_motion_weighted (FunscriptFlow.pyw:761-785), float64 ------------------- */
+ORC_API double orc_radial(const float *flow, int w, int h, double cx, double cy, int is_cut, int pov_mode) {
+    if (is_cut) return 0.0;
+    double s = 0;
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            size_t o = (size_t)y * w + x;
+            double dx = x - cx, dy = y - cy;
+            double dot = (double)flow[o * 2] * dx + (double)flow[o * 2 + 1] * dy;
+            if (!pov_mode) {
+                dot = (x > cx) ? dot * (double)(w - x) / (double)w : dot * (double)x / (double)w;
+                dot = (y > cy) ? dot * (double)(h - y) / (double)h : dot * (double)y / (double)h;
+            }
+            s += dot;
+        }
+    return s / ((double)w * h);
+}
+
+/* ---- whole pair, as bench.py's cpu_baseline leg times it ------------------------------ */
+ORC_API int orc_pair(const uint8_t *prev, const uint8_t *next, int w, int h, int stride, float *flow, int *ox,
+                     int *oy, float *oval, double *mean_mag) {
+    int rc = orc_farneback(prev, next, w, h, stride, flow);
+    if (rc) return rc;
+    orc_max_divergence(flow, w, h, ox, oy, oval);
+    *mean_mag = orc_mean_mag(flow, w, h);
+    return 0;
+}

@@ -1,0 +1,147 @@
+"""Known-answer tests pinning the C restatement of cv2.calcOpticalFlowFarneback (FunscriptFlow.pyw:878-879).
+
+The arithmetic lives in opencv-python 4.11.0.86 (uv.lock:238-239), which is absent from
+/root/reference and from this image, and the reference holds no fixture for it: PARITY UNPINNED
+against cv2.  These tests pin the restatement against analytic answers only."""
+import numpy as np
+import pytest
+
+import oracle as orc
+from funscript_flow_amd.synth import sine_translate_frames
+
+
+def test_level_logic():
+    # all BASELINE sizes use 3 extra scales; sigma/ksize = 3.5/19, 1.5/9, 0.5/3, 0/3
+    for (w, h), sizes in {(256, 256): [(32, 32), (64, 64), (128, 128), (256, 256)],
+                          (640, 360): [(80, 45), (160, 90), (320, 180), (640, 360)],
+                          (1920, 1080): [(240, 135), (480, 270), (960, 540), (1920, 1080)],
+                          (3840, 2160): [(480, 270), (960, 540), (1920, 1080), (3840, 2160)]}.items():
+        assert orc.num_levels(w, h) == 3
+        got = [orc.level_params(w, h, k) for k in (3, 2, 1, 0)]
+        assert [(g[0], g[1]) for g in got] == sizes
+        assert [(g[2], g[3]) for g in got] == [(3.5, 19), (1.5, 9), (0.5, 3), (0.0, 3)]
+    # min_size = 32 stops the pyramid early for small images
+    assert orc.num_levels(100, 60) == 0      # 60*0.5 = 30 < 32
+    assert orc.num_levels(130, 64) == 1
+    assert orc.num_levels(255, 255) == 2     # 255/8 = 31.9 < 32
+
+
+def test_gaussian_kernels():
+    assert np.array_equal(orc.gaussian_kernel(3, 0.0), np.float32([0.25, 0.5, 0.25]))
+    k = orc.gaussian_kernel(3, 0.5)
+    assert np.allclose(k, [0.10650698, 0.78698604, 0.10650698], atol=1e-8)
+    for n, s in ((9, 1.5), (19, 3.5)):
+        k = orc.gaussian_kernel(n, s)
+        assert abs(k.sum() - 1) < 1e-6 and np.array_equal(k, k[::-1]) and k.argmax() == n // 2
+
+
+def test_polyexp_constants():
+    g, xg, xxg, ig = orc.polyexp_constants()
+    assert np.allclose(ig, [0.6944863967, -0.3474535354, 0.2413017476, 0.4823113438], rtol=0, atol=2e-8)  # survey value came from a float64-product transcription
+    assert abs(g[0] + 2 * g[1:].sum() - 1) < 1e-6
+    assert np.array_equal(xg, (np.arange(6) * g).astype(np.float32))
+
+
+def test_polyexp_quadratic_known_answer():
+    """I = a + bx + cy + dx^2 + ey^2 + fxy  =>  interior R = (c', b', e, d, f) with first-order
+    coefficients taken about the probe pixel (channel order [dy, dx, yy, xx, xy])."""
+    h, w = 40, 48
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    a, b, c, d, e, f = 3.0, 0.5, -0.25, 0.02, -0.03, 0.015
+    I = (a + b * x + c * y + d * x * x + e * y * y + f * x * y).astype(np.float32)
+    R = orc.polyexp(I)
+    ys, xs = slice(8, h - 8), slice(8, w - 8)
+    yy, xx = y[ys, xs], x[ys, xs]
+    assert np.allclose(R[0][ys, xs], c + 2 * e * yy + f * xx, atol=2e-4)
+    assert np.allclose(R[1][ys, xs], b + 2 * d * xx + f * yy, atol=2e-4)
+    assert np.allclose(R[2][ys, xs], e, atol=2e-4)
+    assert np.allclose(R[3][ys, xs], d, atol=2e-4)
+    assert np.allclose(R[4][ys, xs], f, atol=2e-4)
+
+
+def test_resize_rules():
+    import ctypes as C
+    L = orc.lib()
+
+    def table(src, dst):
+        i0, i1, f = np.empty(dst, np.int32), np.empty(dst, np.int32), np.empty(dst, np.float32)
+        L.orc_resize_table(src, dst, i0.ctypes.data_as(C.c_void_p), i1.ctypes.data_as(C.c_void_p),
+                           f.ctypes.data_as(C.c_void_p))
+        return i0, i1, f
+
+    i0, i1, f = table(64, 32)          # down by 2: mean of 2d, 2d+1
+    assert np.array_equal(i0, 2 * np.arange(32)) and np.array_equal(i1, i0 + 1) and np.all(f == 0.5)
+    i0, i1, f = table(64, 16)          # down by 4: 4d+1, 4d+2
+    assert np.array_equal(i0, 4 * np.arange(16) + 1) and np.all(f == 0.5)
+    i0, i1, f = table(64, 8)           # down by 8: 8d+3, 8d+4
+    assert np.array_equal(i0, 8 * np.arange(8) + 3) and np.all(f == 0.5)
+    i0, i1, f = table(32, 32)          # same size: copy
+    assert np.array_equal(i0, np.arange(32)) and np.all(f == 0)
+    i0, i1, f = table(16, 32)          # up by 2: .25/.75 with clamped edges
+    assert i0[0] == 0 and f[0] == 0 and f[1] == 0.25 and f[2] == 0.75 and i0[31] == 15 and f[31] == 0
+
+
+def test_pyr_level0_is_3tap_blur():
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (40, 56), dtype=np.uint8)
+    I = orc.pyr_level(img, 0)
+    p = np.pad(img.astype(np.float32), 1, mode="reflect")
+    hb = 0.5 * p[:, 1:-1] + 0.25 * (p[:, :-2] + p[:, 2:])
+    vb = 0.5 * hb[1:-1] + 0.25 * (hb[:-2] + hb[2:])
+    assert np.array_equal(I, vb.astype(np.float32))
+
+
+def test_identical_frames_h_vanishes_in_bounds():
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    R = orc.polyexp(orc.pyr_level(img, 0))
+    M = orc.update_matrices(R, R, np.zeros((48, 64, 2), np.float32))
+    assert np.all(M[3][:-1, :-1] == 0) and np.all(M[4][:-1, :-1] == 0)
+    assert np.any(M[3][-1, :] != 0)  # last row takes the out-of-bounds branch (SURVEY A.7 caveat)
+
+
+@pytest.mark.parametrize("shift", [(2.3, -1.1), (-6.0, 3.5), (0.4, 0.0)])
+def test_translation_recovered(shift):
+    """interior median flow ~ the true translation (Farneback under-estimates slightly)."""
+    w, h = 320, 180
+    rng = np.random.default_rng(11)
+    a, fx, fy, ph = rng.uniform(5, 25, 12), rng.uniform(0.02, 0.25, 12), rng.uniform(0.02, 0.25, 12), rng.uniform(0, 6.28, 12)
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+
+    def frame(dx, dy):
+        f = 128 + sum(a[i] * np.sin(fx[i] * (x - dx) + fy[i] * (y - dy) + ph[i]) for i in range(12))
+        return np.clip(np.rint(f), 0, 255).astype(np.uint8)
+
+    flow = orc.farneback(frame(0, 0), frame(*shift))
+    med = np.median(flow[40:-40, 40:-40].reshape(-1, 2), axis=0)
+    assert abs(med[0] - shift[0]) <= 0.06 * abs(shift[0]) + 0.05
+    assert abs(med[1] - shift[1]) <= 0.06 * abs(shift[1]) + 0.05
+
+
+def test_steps_compose_to_driver():
+    """The step functions the GPU parity tests use reproduce orc_farneback exactly."""
+    fr = sine_translate_frames(2, 96, 80, seed=4, amp=(2.0, 1.5), period=7)
+    w, h = 96, 80
+    levels = orc.num_levels(w, h)
+    flow = None
+    for k in range(levels, -1, -1):
+        lw, lh, _, _ = orc.level_params(w, h, k)
+        flow = np.zeros((lh, lw, 2), np.float32) if flow is None else orc.flow_upsample(flow, lw, lh)
+        R0, R1 = orc.polyexp(orc.pyr_level(fr[0], k)), orc.polyexp(orc.pyr_level(fr[1], k))
+        M = orc.update_matrices(R0, R1, flow)
+        for it in range(3):
+            flow = orc.blur_solve(M)
+            if it < 2:
+                M = orc.update_matrices(R0, R1, flow)
+    assert np.array_equal(flow, orc.farneback(fr[0], fr[1]))
+    d = orc.farneback_dbg(fr[0], fr[1], 0, 3)
+    assert np.array_equal(d["out"], flow) and np.array_equal(d["flow"], flow)
+
+
+def test_bgr2gray_fixed_point():
+    rng = np.random.default_rng(9)
+    bgr = rng.integers(0, 256, (20, 30, 3), dtype=np.uint8)
+    g = orc.bgr2gray(bgr)
+    b, gg, r = (bgr[..., i].astype(np.int64) for i in range(3))
+    assert np.array_equal(g, ((b * 3735 + gg * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8))
+    assert np.array_equal(orc.bgr2gray(np.full((4, 4, 3), 255, np.uint8)), np.full((4, 4), 255, np.uint8))
