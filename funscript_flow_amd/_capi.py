@@ -1,0 +1,189 @@
+"""ctypes binding of libffl_hip.so (include/ffl.h).  No fallback: if the HIP library is missing or no
+device is usable, loading / context creation raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libffl_hip.so")
+
+FFL_OK = 0
+FFL_MAX_BATCH = 32
+KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "k_flow_upsample", "k_update_matrices", "k_blur_solve",
+                  "k_pass1", "k_radial"]
+
+# every symbol include/ffl.h declares (tests check that the library exports all of them)
+EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "ffl_upload_frame", "ffl_flow_pairs",
+           "ffl_pass1_result", "ffl_radial", "ffl_download_flow", "ffl_upload_flow", "ffl_submit_pair", "ffl_sync",
+           "ffl_num_levels", "ffl_level_size", "ffl_debug_pair", "ffl_profile_enable", "ffl_profile_read",
+           "ffl_kernel_name"]
+
+
+class FFLError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load libffl_hip.so; raises FFLError if it has not been built (see __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FFLError(f"{LIB_PATH} is missing: build it with `make -C funscript_flow_amd/csrc` "
+                       "(there is no CPU fallback for the HIP backend)")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_double)
+    L.ffl_device_count.restype = C.c_int
+    L.ffl_create.argtypes = [C.c_int] * 6 + [C.POINTER(vp)]
+    L.ffl_destroy.argtypes = [vp]
+    L.ffl_destroy.restype = None
+    L.ffl_last_error.argtypes = [vp]
+    L.ffl_last_error.restype = C.c_char_p
+    L.ffl_upload_frame.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t]
+    L.ffl_flow_pairs.argtypes = [vp, C.c_int, ip, ip, ip, C.c_int]
+    L.ffl_pass1_result.argtypes = [vp, C.c_int, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                   C.POINTER(C.c_float), C.POINTER(C.c_float), ip]
+    L.ffl_radial.argtypes = [vp, C.c_int, ip, dp, dp, ip, C.c_int, dp]
+    L.ffl_download_flow.argtypes = [vp, C.c_int, vp]
+    L.ffl_upload_flow.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.ffl_submit_pair.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_int]
+    L.ffl_sync.argtypes = [vp]
+    L.ffl_num_levels.argtypes = [vp]
+    L.ffl_level_size.argtypes = [vp, C.c_int, ip]
+    L.ffl_debug_pair.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 6
+    L.ffl_profile_enable.argtypes = [vp, C.c_int]
+    L.ffl_profile_read.argtypes = [vp, C.c_int, ip, dp]
+    L.ffl_kernel_name.argtypes = [C.c_int]
+    L.ffl_kernel_name.restype = C.c_char_p
+    _lib = L
+    return L
+
+
+def device_count():
+    return load().ffl_device_count()
+
+
+def _iarr(v):
+    return (C.c_int * len(v))(*[int(x) for x in v])
+
+
+def _darr(v):
+    return (C.c_double * len(v))(*[float(x) for x in v])
+
+
+class Context:
+    """One device context for frames of a fixed size (ffl_create / ffl_destroy)."""
+
+    def __init__(self, width, height, device=0, frame_slots=None, flow_slots=None, max_batch=8):
+        self.L = load()
+        self.width, self.height, self.device, self.max_batch = int(width), int(height), int(device), int(max_batch)
+        self.frame_slots = int(frame_slots if frame_slots is not None else 2 * max_batch + 2)
+        self.flow_slots = int(flow_slots if flow_slots is not None else 13 + 2 * max_batch)
+        h = C.c_void_p()
+        rc = self.L.ffl_create(self.device, self.width, self.height, self.frame_slots, self.flow_slots, self.max_batch,
+                               C.byref(h))
+        if rc != FFL_OK:
+            raise FFLError(f"ffl_create failed ({rc}): {self.L.ffl_last_error(None).decode()}")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.ffl_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _chk(self, rc):
+        if rc != FFL_OK:
+            raise FFLError(f"ffl error {rc}: {self.L.ffl_last_error(self._h).decode()}")
+
+    # ---- frames -------------------------------------------------------------------------------
+    def upload_frame(self, fslot, frame):
+        """frame: C-contiguous-rows uint8 (H,W) gray or (H,W,3) BGR, exactly what cv2 hands Python."""
+        if frame.dtype != np.uint8 or frame.ndim not in (2, 3):
+            raise FFLError("frame must be uint8 (H,W) or (H,W,3)")
+        ch = 1 if frame.ndim == 2 else frame.shape[2]
+        if frame.strides[-1] != 1 or (frame.ndim == 3 and frame.strides[1] != ch):
+            frame = np.ascontiguousarray(frame)
+        self._chk(self.L.ffl_upload_frame(self._h, fslot, frame.ctypes.data, frame.shape[1], frame.shape[0], ch,
+                                          frame.strides[0]))
+
+    def flow_pairs(self, fslot0, fslot1, flow_slots, pov_mode=False):
+        n = len(flow_slots)
+        self._chk(self.L.ffl_flow_pairs(self._h, n, _iarr(fslot0), _iarr(fslot1), _iarr(flow_slots), int(bool(pov_mode))))
+
+    def submit_pair(self, slot, prev, nxt, pov_mode=False):
+        prev, nxt = np.ascontiguousarray(prev), np.ascontiguousarray(nxt)
+        ch = 1 if prev.ndim == 2 else prev.shape[2]
+        self._chk(self.L.ffl_submit_pair(self._h, slot, prev.ctypes.data, nxt.ctypes.data, prev.shape[1], prev.shape[0],
+                                         ch, prev.strides[0], int(bool(pov_mode))))
+
+    def pass1_result(self, flow_slot, cut_threshold=7.0):
+        x, y, c = C.c_int32(), C.c_int32(), C.c_int()
+        v, mm = C.c_float(), C.c_float()
+        self._chk(self.L.ffl_pass1_result(self._h, flow_slot, float(cut_threshold), C.byref(x), C.byref(y), C.byref(v),
+                                          C.byref(mm), C.byref(c)))
+        return x.value, y.value, np.float32(v.value), np.float32(mm.value), bool(c.value)
+
+    def radial(self, flow_slots, centers, is_cut, pov_mode=False):
+        n = len(flow_slots)
+        out = (C.c_double * n)()
+        self._chk(self.L.ffl_radial(self._h, n, _iarr(flow_slots), _darr([c[0] for c in centers]),
+                                    _darr([c[1] for c in centers]), _iarr([int(bool(c)) for c in is_cut]),
+                                    int(bool(pov_mode)), out))
+        return [float(v) for v in out]
+
+    def download_flow(self, flow_slot):
+        out = np.empty((self.height, self.width, 2), np.float32)
+        self._chk(self.L.ffl_download_flow(self._h, flow_slot, out.ctypes.data))
+        return out
+
+    def upload_flow(self, flow_slot, flow, pov_mode=False):
+        flow = np.ascontiguousarray(flow, np.float32)
+        if flow.shape != (self.height, self.width, 2):
+            raise FFLError(f"flow shape {flow.shape} does not match context {(self.height, self.width, 2)}")
+        self._chk(self.L.ffl_upload_flow(self._h, flow_slot, flow.ctypes.data, int(bool(pov_mode))))
+
+    def sync(self):
+        self._chk(self.L.ffl_sync(self._h))
+
+    # ---- test / measurement hooks --------------------------------------------------------------
+    def num_levels(self):
+        return self.L.ffl_num_levels(self._h)
+
+    def level_size(self, level):
+        wh = (C.c_int * 2)()
+        self._chk(self.L.ffl_level_size(self._h, level, wh))
+        return wh[0], wh[1]
+
+    def debug_pair(self, f0, f1, level, it):
+        lw, lh = self.level_size(level)
+        d = dict(I0=np.empty((lh, lw), np.float32), I1=np.empty((lh, lw), np.float32),
+                 R0=np.empty((5, lh, lw), np.float32), R1=np.empty((5, lh, lw), np.float32),
+                 M=np.empty((5, lh, lw), np.float32), flow=np.empty((lh, lw, 2), np.float32))
+        self._chk(self.L.ffl_debug_pair(self._h, f0, f1, level, it, d["I0"].ctypes.data, d["I1"].ctypes.data,
+                                        d["R0"].ctypes.data, d["R1"].ctypes.data, d["M"].ctypes.data,
+                                        d["flow"].ctypes.data))
+        d["out"] = self.download_flow(0)
+        return d
+
+    def profile_enable(self, on=True):
+        self._chk(self.L.ffl_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        out = {}
+        for k, name in enumerate(KERNEL_CLASSES):
+            n, ms = C.c_int(), C.c_double()
+            self._chk(self.L.ffl_profile_read(self._h, k, C.byref(n), C.byref(ms)))
+            out[name] = (n.value, ms.value)
+        return out

@@ -1,0 +1,649 @@
+// C ABI (include/ffl.h) of the gfx950 pair-motion path: context, slots, streams, batch schedule.
+//
+// Streams: `copy` carries the pinned H2D frame transfers (+ the BGR->gray kernel); `compute`
+// carries everything else.  compute waits on a frame's upload event; an upload into a frame slot
+// waits on the event of the last batch that read it.  No host synchronisation happens inside
+// ffl_upload_frame / ffl_flow_pairs, so uploads of the next frames overlap the kernels of the
+// previous batch (north_star: "staged to HBM via pinned hipMemcpyAsync on a side stream").
+#include "../../include/ffl.h"
+#include "ffl_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+static thread_local std::string g_create_error = "";
+
+struct ProfRec {
+    int cls;
+    hipEvent_t a, b;
+};
+
+struct LevelGeom {
+    int lw, lh, ksize;
+    double sigma;
+    GaussKernel gk;
+};
+
+struct ffl_ctx {
+    int device = 0, w = 0, h = 0, levels = 0;
+    int n_fslots = 0, n_slots = 0, max_batch = 0;
+    size_t N = 0;
+    LevelGeom geom[8];
+    PolyConsts pc;
+    hipStream_t s_copy = nullptr, s_compute = nullptr;
+    // frames
+    uint8_t *d_gray = nullptr;        // [n_fslots][N]
+    uint8_t *d_bgr = nullptr;         // [n_fslots][3N] staging for 3-channel uploads
+    uint8_t *h_stage = nullptr;       // pinned [n_fslots][3N]
+    std::vector<hipEvent_t> ev_uploaded, ev_last_use;
+    std::vector<char> frame_valid;
+    // work buffers
+    float *d_I = nullptr, *d_R = nullptr, *d_M[2] = {nullptr, nullptr}, *d_flowA = nullptr, *d_flowB = nullptr;
+    // flow slots
+    float *d_flow = nullptr;          // [n_slots][2N]
+    Pass1Result *d_res = nullptr;     // [n_slots]
+    Pass1Result *h_res = nullptr;     // pinned [n_slots]
+    std::vector<hipEvent_t> ev_slot_done;
+    std::vector<char> slot_state;     // 0 empty, 1 queued/ready
+    std::vector<char> slot_pov;
+    unsigned long long *d_pkey = nullptr;
+    double *d_psum = nullptr, *d_radial = nullptr, *h_radial = nullptr;
+    int p1_blocks = 0;
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> prof_recs;
+    int prof_launches[FFL_K_COUNT] = {0};
+    double prof_ms[FFL_K_COUNT] = {0};
+    std::string err;
+};
+
+static int set_err(ffl_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return set_err(c, FFL_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, \
+                           __LINE__);                                                                     \
+    } while (0)
+
+// ---- host-side constants (same published procedure as OpenCV's helpers) -------------------------
+static inline int cv_round(double v) { return (int)lrint(v); }
+
+static void gaussian_kernel(int n, double sigma, float *out) {  // getGaussianKernel(n, sigma, CV_32F)
+    static const float tab1[] = {1.f};
+    static const float tab3[] = {0.25f, 0.5f, 0.25f};
+    static const float tab5[] = {0.0625f, 0.25f, 0.375f, 0.25f, 0.0625f};
+    static const float tab7[] = {0.03125f, 0.109375f, 0.21875f, 0.28125f, 0.21875f, 0.109375f, 0.03125f};
+    const float *fixed = nullptr;
+    if (sigma <= 0 && (n & 1) && n <= 7) fixed = n == 1 ? tab1 : n == 3 ? tab3 : n == 5 ? tab5 : tab7;
+    double sg = sigma > 0 ? sigma : ((n - 1) * 0.5 - 1) * 0.3 + 0.8;
+    double scale2x = -0.5 / (sg * sg);
+    double sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        double t = fixed ? (double)fixed[i] : exp(scale2x * x * x);
+        out[i] = (float)t;
+        sum += out[i];
+    }
+    sum = 1.0 / sum;
+    for (int i = 0; i < n; i++) out[i] = (float)(out[i] * sum);
+}
+
+static void polyexp_prepare(PolyConsts *pc) {  // FarnebackPrepareGaussian(n = 5, sigma = 1.2)
+    const int n = FFL_POLY_N;
+    const double sigma = 1.2;
+    float gg[2 * FFL_POLY_N + 1];
+    double s = 0;
+    for (int x = -n; x <= n; x++) {
+        gg[x + n] = (float)exp(-x * x / (2 * sigma * sigma));
+        s += gg[x + n];
+    }
+    s = 1. / s;
+    for (int x = -n; x <= n; x++) gg[x + n] = (float)(gg[x + n] * s);
+    for (int x = 0; x <= n; x++) {
+        pc->g[x] = gg[x + n];
+        pc->xg[x] = (float)(x * gg[x + n]);
+        pc->xxg[x] = (float)(x * x * gg[x + n]);
+    }
+    double G[6][6];
+    memset(G, 0, sizeof(G));
+    for (int y = -n; y <= n; y++)
+        for (int x = -n; x <= n; x++) {
+            float p = gg[y + n] * gg[x + n];
+            G[0][0] += p;
+            G[1][1] += p * x * x;
+            G[3][3] += p * x * x * x * x;
+            G[5][5] += p * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    double A[6][12];
+    for (int i = 0; i < 6; i++)
+        for (int j = 0; j < 12; j++) A[i][j] = j < 6 ? G[i][j] : (j - 6 == i ? 1.0 : 0.0);
+    for (int c = 0; c < 6; c++) {
+        int p = c;
+        for (int r = c + 1; r < 6; r++)
+            if (fabs(A[r][c]) > fabs(A[p][c])) p = r;
+        if (p != c)
+            for (int j = 0; j < 12; j++) { double t = A[c][j]; A[c][j] = A[p][j]; A[p][j] = t; }
+        double d = 1.0 / A[c][c];
+        for (int j = 0; j < 12; j++) A[c][j] *= d;
+        for (int r = 0; r < 6; r++)
+            if (r != c) {
+                double f = A[r][c];
+                if (f != 0)
+                    for (int j = 0; j < 12; j++) A[r][j] -= f * A[c][j];
+            }
+    }
+    pc->ig11 = A[1][7];
+    pc->ig03 = A[0][9];
+    pc->ig33 = A[3][9];
+    pc->ig55 = A[5][11];
+}
+
+static void level_geometry(ffl_ctx *c) {  // FarnebackOpticalFlowImpl::calc level logic
+    int k;
+    double scale = 1.0;
+    for (k = 0; k < 3; k++) {
+        scale *= 0.5;
+        if (c->w * scale < 32 || c->h * scale < 32) break;
+    }
+    c->levels = k;
+    for (k = 0; k <= c->levels; k++) {
+        double sc = 1.0;
+        for (int i = 0; i < k; i++) sc *= 0.5;
+        LevelGeom &g = c->geom[k];
+        g.sigma = (1.0 / sc - 1.0) * 0.5;
+        int sm = cv_round(g.sigma * 5) | 1;
+        g.ksize = sm < 3 ? 3 : sm;
+        g.lw = cv_round(c->w * sc);
+        g.lh = cv_round(c->h * sc);
+        memset(&g.gk, 0, sizeof(g.gk));
+        g.gk.ksize = g.ksize;
+        gaussian_kernel(g.ksize, g.sigma, g.gk.k);
+    }
+}
+
+// ---- profiling helpers ---------------------------------------------------------------------------
+struct ProfScope {
+    ffl_ctx *c;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    ProfScope(ffl_ctx *c_, int cls_, hipStream_t st) : c(c_), cls(cls_) {
+        if (c->prof) {
+            hipEventCreate(&a);
+            hipEventCreate(&b);
+            hipEventRecord(a, st);
+            stream = st;
+        }
+    }
+    ~ProfScope() {
+        if (c->prof) {
+            hipEventRecord(b, stream);
+            c->prof_recs.push_back({cls, a, b});
+        }
+    }
+    hipStream_t stream = nullptr;
+};
+
+static void prof_collect(ffl_ctx *c) {
+    for (auto &r : c->prof_recs) {
+        float ms = 0;
+        hipEventSynchronize(r.b);
+        hipEventElapsedTime(&ms, r.a, r.b);
+        c->prof_launches[r.cls]++;
+        c->prof_ms[r.cls] += ms;
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    c->prof_recs.clear();
+}
+
+// ---- API -----------------------------------------------------------------------------------------
+extern "C" {
+
+int ffl_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+const char *ffl_last_error(const ffl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+const char *ffl_kernel_name(int k) {
+    static const char *names[FFL_K_COUNT] = {"k_gray",  "k_pyr_level", "k_polyexp", "k_flow_upsample",
+                                             "k_update_matrices", "k_blur_solve", "k_pass1", "k_radial"};
+    return (k >= 0 && k < FFL_K_COUNT) ? names[k] : "?";
+}
+
+void ffl_destroy(ffl_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->s_compute) hipStreamSynchronize(c->s_compute);
+    if (c->s_copy) hipStreamSynchronize(c->s_copy);
+    prof_collect(c);
+    for (auto e : c->ev_uploaded) hipEventDestroy(e);
+    for (auto e : c->ev_last_use) hipEventDestroy(e);
+    for (auto e : c->ev_slot_done) hipEventDestroy(e);
+    hipFree(c->d_gray); hipFree(c->d_bgr); hipHostFree(c->h_stage);
+    hipFree(c->d_I); hipFree(c->d_R); hipFree(c->d_M[0]); hipFree(c->d_M[1]);
+    hipFree(c->d_flowA); hipFree(c->d_flowB); hipFree(c->d_flow); hipFree(c->d_res);
+    hipHostFree(c->h_res);
+    hipFree(c->d_pkey); hipFree(c->d_psum); hipFree(c->d_radial); hipHostFree(c->h_radial);
+    if (c->s_copy) hipStreamDestroy(c->s_copy);
+    if (c->s_compute) hipStreamDestroy(c->s_compute);
+    delete c;
+}
+
+int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_slots, int max_batch,
+               ffl_ctx **out) {
+    if (!out) return set_err(nullptr, FFL_ERR_INVALID, "ffl_create: out is NULL");
+    *out = nullptr;
+    if (width < 16 || height < 16 || (long)width * height > (1L << 31) - 1)
+        return set_err(nullptr, FFL_ERR_INVALID, "ffl_create: unsupported frame size %dx%d", width, height);
+    if (n_frame_slots < 2 || n_flow_slots < 1 || max_batch < 1 || max_batch > FFL_MAX_BATCH)
+        return set_err(nullptr, FFL_ERR_INVALID, "ffl_create: bad slot/batch counts (%d, %d, %d)", n_frame_slots,
+                       n_flow_slots, max_batch);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_err(nullptr, FFL_ERR_NO_DEVICE, "ffl_create: no HIP device available (this library has no CPU path)");
+    if (device < 0 || device >= ndev)
+        return set_err(nullptr, FFL_ERR_INVALID, "ffl_create: device %d out of range (0..%d)", device, ndev - 1);
+    ffl_ctx *c = new ffl_ctx();
+    c->device = device;
+    c->w = width;
+    c->h = height;
+    c->N = (size_t)width * height;
+    c->n_fslots = n_frame_slots;
+    c->n_slots = n_flow_slots;
+    c->max_batch = max_batch;
+    level_geometry(c);
+    polyexp_prepare(&c->pc);
+#define CCHK(call)                                                                                       \
+    do {                                                                                                 \
+        hipError_t e_ = (call);                                                                          \
+        if (e_ != hipSuccess) {                                                                          \
+            int rc_ = set_err(nullptr, FFL_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));      \
+            ffl_destroy(c);                                                                              \
+            return rc_;                                                                                  \
+        }                                                                                                \
+    } while (0)
+    CCHK(hipSetDevice(device));
+    CCHK(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
+    CCHK(hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking));
+    const size_t N = c->N;
+    const int maxU = 2 * max_batch;
+    CCHK(hipMalloc(&c->d_gray, (size_t)n_frame_slots * N));
+    CCHK(hipMalloc(&c->d_bgr, (size_t)n_frame_slots * N * 3));
+    CCHK(hipHostMalloc(&c->h_stage, (size_t)n_frame_slots * N * 3, hipHostMallocDefault));
+    CCHK(hipMalloc(&c->d_I, sizeof(float) * N * maxU));
+    CCHK(hipMalloc(&c->d_R, sizeof(float) * 5 * N * maxU));
+    CCHK(hipMalloc(&c->d_M[0], sizeof(float) * 5 * N * max_batch));
+    CCHK(hipMalloc(&c->d_M[1], sizeof(float) * 5 * N * max_batch));
+    CCHK(hipMalloc(&c->d_flowA, sizeof(float) * 2 * N * max_batch));
+    CCHK(hipMalloc(&c->d_flowB, sizeof(float) * 2 * N * max_batch));
+    CCHK(hipMalloc(&c->d_flow, sizeof(float) * 2 * N * n_flow_slots));
+    CCHK(hipMalloc(&c->d_res, sizeof(Pass1Result) * n_flow_slots));
+    CCHK(hipHostMalloc(&c->h_res, sizeof(Pass1Result) * n_flow_slots, hipHostMallocDefault));
+    c->p1_blocks = ffl_pass1_blocks(width, height);
+    CCHK(hipMalloc(&c->d_pkey, sizeof(unsigned long long) * c->p1_blocks * FFL_MAXB));
+    CCHK(hipMalloc(&c->d_psum, sizeof(double) * c->p1_blocks * FFL_MAXB));
+    CCHK(hipMalloc(&c->d_radial, sizeof(double) * FFL_MAXB));
+    CCHK(hipHostMalloc(&c->h_radial, sizeof(double) * FFL_MAXB, hipHostMallocDefault));
+    c->ev_uploaded.resize(n_frame_slots);
+    c->ev_last_use.resize(n_frame_slots);
+    c->frame_valid.assign(n_frame_slots, 0);
+    for (int i = 0; i < n_frame_slots; i++) {
+        CCHK(hipEventCreateWithFlags(&c->ev_uploaded[i], hipEventDisableTiming));
+        CCHK(hipEventCreateWithFlags(&c->ev_last_use[i], hipEventDisableTiming));
+    }
+    c->ev_slot_done.resize(n_flow_slots);
+    c->slot_state.assign(n_flow_slots, 0);
+    c->slot_pov.assign(n_flow_slots, 0);
+    for (int i = 0; i < n_flow_slots; i++) CCHK(hipEventCreateWithFlags(&c->ev_slot_done[i], hipEventDisableTiming));
+#undef CCHK
+    *out = c;
+    return FFL_OK;
+}
+
+int ffl_num_levels(const ffl_ctx *c) { return c ? c->levels : -1; }
+
+int ffl_level_size(const ffl_ctx *c, int level, int *out_wh) {
+    if (!c || !out_wh || level < 0 || level > c->levels) return FFL_ERR_INVALID;
+    out_wh[0] = c->geom[level].lw;
+    out_wh[1] = c->geom[level].lh;
+    return FFL_OK;
+}
+
+int ffl_upload_frame(ffl_ctx *c, int fslot, const uint8_t *data, int width, int height, int channels,
+                     ptrdiff_t stride_bytes) {
+    if (!c) return FFL_ERR_INVALID;
+    if (!data || fslot < 0 || fslot >= c->n_fslots)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frame: bad frame slot %d", fslot);
+    if (width != c->w || height != c->h)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frame: frame is %dx%d, context is %dx%d", width, height, c->w, c->h);
+    if (channels != 1 && channels != 3)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frame: channels must be 1 (gray) or 3 (BGR), got %d", channels);
+    if (stride_bytes < (ptrdiff_t)width * channels)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frame: stride %td < row bytes %d", stride_bytes, width * channels);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = c->N, row = (size_t)width * channels;
+    uint8_t *stage = c->h_stage + (size_t)fslot * N * 3;
+    // the previous transfer out of this staging area must have left the host buffer
+    if (c->frame_valid[fslot]) HIPCHK(c, hipEventSynchronize(c->ev_uploaded[fslot]));
+    if ((size_t)stride_bytes == row) memcpy(stage, data, row * height);
+    else
+        for (int y = 0; y < height; y++) memcpy(stage + (size_t)y * row, data + (ptrdiff_t)y * stride_bytes, row);
+    // the device copy of this slot may still be read by a queued batch
+    HIPCHK(c, hipStreamWaitEvent(c->s_copy, c->ev_last_use[fslot], 0));
+    uint8_t *gray = c->d_gray + (size_t)fslot * N;
+    if (channels == 1) {
+        HIPCHK(c, hipMemcpyAsync(gray, stage, N, hipMemcpyHostToDevice, c->s_copy));
+    } else {
+        uint8_t *bgr = c->d_bgr + (size_t)fslot * N * 3;
+        HIPCHK(c, hipMemcpyAsync(bgr, stage, N * 3, hipMemcpyHostToDevice, c->s_copy));
+        ProfScope ps(c, FFL_K_GRAY, c->s_copy);
+        ffl_launch_gray(bgr, gray, (int)N, c->s_copy);
+    }
+    HIPCHK(c, hipEventRecord(c->ev_uploaded[fslot], c->s_copy));
+    c->frame_valid[fslot] = 1;
+    return FFL_OK;
+}
+
+struct DebugCapture {
+    int level, iter;
+    float *I0, *I1, *R0, *R1, *M, *flow;
+};
+
+// One batch of pairs through the 4-scale Farneback schedule + pass-1 reductions (compute stream).
+static int run_batch(ffl_ctx *c, int n, const int *f0, const int *f1, const int *slots, int pov_mode,
+                     const DebugCapture *cap) {
+    hipStream_t st = c->s_compute;
+    const size_t N = c->N;
+    // unique frames of the batch
+    UTab ut;
+    PairTab pt;
+    memset(&ut, 0, sizeof(ut));
+    memset(&pt, 0, sizeof(pt));
+    int nU = 0;
+    auto uidx = [&](int fs) {
+        for (int i = 0; i < nU; i++)
+            if (ut.fslot[i] == fs) return i;
+        ut.fslot[nU] = fs;
+        return nU++;
+    };
+    for (int i = 0; i < n; i++) {
+        pt.u0[i] = uidx(f0[i]);
+        pt.u1[i] = uidx(f1[i]);
+    }
+    for (int i = 0; i < nU; i++) HIPCHK(c, hipStreamWaitEvent(st, c->ev_uploaded[ut.fslot[i]], 0));
+
+    float *cur = c->d_flowA, *prv = c->d_flowB;
+    int pw = 0, ph = 0;
+    for (int k = c->levels; k >= 0; k--) {
+        const LevelGeom &g = c->geom[k];
+        const int lw = g.lw, lh = g.lh;
+        const size_t plane = (size_t)lw * lh;
+        const size_t I_stride = plane, R_stride = 5 * plane, M_stride = 5 * plane;
+        for (int i = 0; i < n; i++) {
+            pt.flow[i] = (k == 0) ? c->d_flow + (size_t)slots[i] * 2 * N : cur + (size_t)i * 2 * plane;
+            pt.prev[i] = prv + (size_t)i * 2 * (size_t)pw * ph;
+        }
+        if (pw == 0) {
+            for (int i = 0; i < n; i++) HIPCHK(c, hipMemsetAsync(pt.flow[i], 0, sizeof(float) * 2 * plane, st));
+        } else {
+            ProfScope ps(c, FFL_K_UPSAMPLE, st);
+            ffl_launch_flow_upsample(pt, n, pw, ph, lw, lh, st);
+        }
+        {
+            ProfScope ps(c, FFL_K_PYRAMID, st);
+            ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, lw, lh, g.gk, c->d_I, I_stride, st);
+        }
+        {
+            ProfScope ps(c, FFL_K_POLYEXP, st);
+            ffl_launch_polyexp(c->d_I, I_stride, c->d_R, R_stride, plane, nU, lw, lh, c->pc, st);
+        }
+        int mi = 0;
+        {
+            ProfScope ps(c, FFL_K_UPDATE_MATRICES, st);
+            ffl_launch_update_matrices(c->d_R, R_stride, plane, pt, n, c->d_M[mi], M_stride, lw, lh, st);
+        }
+        bool captured = false;
+        auto capture = [&]() -> int {
+            HIPCHK(c, hipStreamSynchronize(st));
+            if (cap->I0) HIPCHK(c, hipMemcpy(cap->I0, c->d_I + (size_t)pt.u0[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
+            if (cap->I1) HIPCHK(c, hipMemcpy(cap->I1, c->d_I + (size_t)pt.u1[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
+            if (cap->R0) HIPCHK(c, hipMemcpy(cap->R0, c->d_R + (size_t)pt.u0[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->R1) HIPCHK(c, hipMemcpy(cap->R1, c->d_R + (size_t)pt.u1[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->M) HIPCHK(c, hipMemcpy(cap->M, c->d_M[mi], sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->flow) HIPCHK(c, hipMemcpy(cap->flow, pt.flow[0], sizeof(float) * 2 * plane, hipMemcpyDeviceToHost));
+            captured = true;
+            return FFL_OK;
+        };
+        for (int it = 0; it < 3; it++) {
+            if (cap && cap->level == k && cap->iter == it) {
+                int rc = capture();
+                if (rc) return rc;
+            }
+            const int update = it < 2;
+            {
+                ProfScope ps(c, FFL_K_BLUR_SOLVE, st);
+                ffl_launch_blur_solve(c->d_M[mi], c->d_M[mi ^ 1], M_stride, c->d_R, R_stride, plane, pt, n, lw, lh,
+                                      update, st);
+            }
+            if (update) mi ^= 1;
+        }
+        if (cap && cap->level == k && !captured) {
+            int rc = capture();
+            if (rc) return rc;
+        }
+        float *t = cur;
+        cur = prv;
+        prv = t;
+        pw = lw;
+        ph = lh;
+    }
+    for (int i = 0; i < nU; i++) HIPCHK(c, hipEventRecord(c->ev_last_use[ut.fslot[i]], st));
+
+    // pass 1 on the finished level-0 flows
+    ResTab rtab;
+    memset(&rtab, 0, sizeof(rtab));
+    for (int i = 0; i < n; i++) rtab.r[i] = c->d_res + slots[i];
+    {
+        ProfScope ps(c, FFL_K_PASS1, st);
+        ffl_launch_pass1(pt, n, c->w, c->h, pov_mode, c->d_pkey, c->d_psum, rtab, st);
+    }
+    for (int i = 0; i < n; i++) {
+        HIPCHK(c, hipMemcpyAsync(c->h_res + slots[i], c->d_res + slots[i], sizeof(Pass1Result), hipMemcpyDeviceToHost, st));
+    }
+    for (int i = 0; i < n; i++) {
+        HIPCHK(c, hipEventRecord(c->ev_slot_done[slots[i]], st));
+        c->slot_state[slots[i]] = 1;
+        c->slot_pov[slots[i]] = (char)(pov_mode != 0);
+    }
+    HIPCHK(c, hipGetLastError());
+    return FFL_OK;
+}
+
+static int check_pairs(ffl_ctx *c, int n, const int *f0, const int *f1, const int *slots) {
+    if (n < 1 || n > c->max_batch) return set_err(c, FFL_ERR_INVALID, "batch of %d pairs, context allows 1..%d", n, c->max_batch);
+    if (!f0 || !f1 || !slots) return set_err(c, FFL_ERR_INVALID, "NULL slot table");
+    for (int i = 0; i < n; i++) {
+        if (f0[i] < 0 || f0[i] >= c->n_fslots || f1[i] < 0 || f1[i] >= c->n_fslots)
+            return set_err(c, FFL_ERR_INVALID, "pair %d: frame slot out of range", i);
+        if (!c->frame_valid[f0[i]] || !c->frame_valid[f1[i]])
+            return set_err(c, FFL_ERR_STATE, "pair %d: frame slot was never uploaded", i);
+        if (slots[i] < 0 || slots[i] >= c->n_slots) return set_err(c, FFL_ERR_INVALID, "pair %d: flow slot out of range", i);
+        for (int j = 0; j < i; j++)
+            if (slots[j] == slots[i]) return set_err(c, FFL_ERR_INVALID, "flow slot %d used twice in one batch", slots[i]);
+    }
+    return FFL_OK;
+}
+
+int ffl_flow_pairs(ffl_ctx *c, int n, const int *fslot0, const int *fslot1, const int *flow_slots, int pov_mode) {
+    if (!c) return FFL_ERR_INVALID;
+    int rc = check_pairs(c, n, fslot0, fslot1, flow_slots);
+    if (rc) return rc;
+    HIPCHK(c, hipSetDevice(c->device));
+    return run_batch(c, n, fslot0, fslot1, flow_slots, pov_mode, nullptr);
+}
+
+int ffl_debug_pair(ffl_ctx *c, int f0, int f1, int level, int iter, float *I0, float *I1, float *R0, float *R1,
+                   float *M, float *flow) {
+    if (!c) return FFL_ERR_INVALID;
+    int slot = 0;
+    int rc = check_pairs(c, 1, &f0, &f1, &slot);
+    if (rc) return rc;
+    if (level < 0 || level > c->levels || iter < 0 || iter > 3) return set_err(c, FFL_ERR_INVALID, "bad level/iter");
+    HIPCHK(c, hipSetDevice(c->device));
+    DebugCapture cap = {level, iter, I0, I1, R0, R1, M, flow};
+    rc = run_batch(c, 1, &f0, &f1, &slot, 0, &cap);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->s_compute));
+    return FFL_OK;
+}
+
+int ffl_pass1_result(ffl_ctx *c, int slot, float cut_threshold, int32_t *x, int32_t *y, float *div_val, float *mean_mag,
+                     int *cut) {
+    if (!c) return FFL_ERR_INVALID;
+    if (slot < 0 || slot >= c->n_slots) return set_err(c, FFL_ERR_INVALID, "flow slot %d out of range", slot);
+    if (!c->slot_state[slot]) return set_err(c, FFL_ERR_STATE, "flow slot %d holds no result", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_slot_done[slot]));
+    const Pass1Result &r = c->h_res[slot];
+    float mm = (float)(r.mag_sum / ((double)c->w * (double)c->h));
+    if (x) *x = r.x;
+    if (y) *y = r.y;
+    if (div_val) *div_val = r.div_val;
+    if (mean_mag) *mean_mag = mm;
+    if (cut) *cut = mm > cut_threshold ? 1 : 0;
+    return FFL_OK;
+}
+
+int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const double *cy, const int *is_cut, int pov_mode,
+               double *out) {
+    if (!c) return FFL_ERR_INVALID;
+    if (n < 1 || n > FFL_MAXB || !slots || !cx || !cy || !out) return set_err(c, FFL_ERR_INVALID, "ffl_radial: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    RadialTab rt;
+    memset(&rt, 0, sizeof(rt));
+    int m = 0;
+    int map[FFL_MAXB];
+    for (int i = 0; i < n; i++) {
+        if (slots[i] < 0 || slots[i] >= c->n_slots) return set_err(c, FFL_ERR_INVALID, "flow slot %d out of range", slots[i]);
+        if (!c->slot_state[slots[i]]) return set_err(c, FFL_ERR_STATE, "flow slot %d holds no flow", slots[i]);
+        if (is_cut && is_cut[i]) {  // FF:766-767: a cut returns 0.0 without looking at the flow
+            out[i] = 0.0;
+            continue;
+        }
+        rt.flow[m] = c->d_flow + (size_t)slots[i] * 2 * c->N;
+        rt.cx[m] = cx[i];
+        rt.cy[m] = cy[i];
+        map[m++] = i;
+    }
+    if (m == 0) return FFL_OK;
+    hipStream_t st = c->s_compute;
+    {
+        ProfScope ps(c, FFL_K_RADIAL, st);
+        ffl_launch_radial(rt, m, c->w, c->h, pov_mode, c->d_psum, c->d_radial, st);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_radial, c->d_radial, sizeof(double) * m, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipGetLastError());
+    for (int j = 0; j < m; j++) out[map[j]] = c->h_radial[j];
+    return FFL_OK;
+}
+
+int ffl_download_flow(ffl_ctx *c, int slot, float *dst) {
+    if (!c) return FFL_ERR_INVALID;
+    if (slot < 0 || slot >= c->n_slots || !dst) return set_err(c, FFL_ERR_INVALID, "ffl_download_flow: bad arguments");
+    if (!c->slot_state[slot]) return set_err(c, FFL_ERR_STATE, "flow slot %d holds no flow", slot);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_slot_done[slot]));
+    HIPCHK(c, hipMemcpy(dst, c->d_flow + (size_t)slot * 2 * c->N, sizeof(float) * 2 * c->N, hipMemcpyDeviceToHost));
+    return FFL_OK;
+}
+
+int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
+    if (!c) return FFL_ERR_INVALID;
+    if (slot < 0 || slot >= c->n_slots || !src) return set_err(c, FFL_ERR_INVALID, "ffl_upload_flow: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t st = c->s_compute;
+    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipMemcpy(c->d_flow + (size_t)slot * 2 * c->N, src, sizeof(float) * 2 * c->N, hipMemcpyHostToDevice));
+    PairTab pt;
+    memset(&pt, 0, sizeof(pt));
+    pt.flow[0] = c->d_flow + (size_t)slot * 2 * c->N;
+    ResTab rtab;
+    memset(&rtab, 0, sizeof(rtab));
+    rtab.r[0] = c->d_res + slot;
+    {
+        ProfScope ps(c, FFL_K_PASS1, st);
+        ffl_launch_pass1(pt, 1, c->w, c->h, pov_mode, c->d_pkey, c->d_psum, rtab, st);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->h_res + slot, c->d_res + slot, sizeof(Pass1Result), hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipEventRecord(c->ev_slot_done[slot], st));
+    c->slot_state[slot] = 1;
+    c->slot_pov[slot] = (char)(pov_mode != 0);
+    HIPCHK(c, hipGetLastError());
+    return FFL_OK;
+}
+
+int ffl_submit_pair(ffl_ctx *c, int slot, const uint8_t *prev, const uint8_t *next, int width, int height, int channels,
+                    ptrdiff_t stride_bytes, int pov_mode) {
+    if (!c) return FFL_ERR_INVALID;
+    if (slot < 0 || 2 * slot + 1 >= c->n_fslots || slot >= c->n_slots)
+        return set_err(c, FFL_ERR_INVALID, "ffl_submit_pair: slot %d needs frame slots %d,%d and a flow slot", slot, 2 * slot, 2 * slot + 1);
+    int rc = ffl_upload_frame(c, 2 * slot, prev, width, height, channels, stride_bytes);
+    if (rc) return rc;
+    rc = ffl_upload_frame(c, 2 * slot + 1, next, width, height, channels, stride_bytes);
+    if (rc) return rc;
+    int f0 = 2 * slot, f1 = 2 * slot + 1;
+    return ffl_flow_pairs(c, 1, &f0, &f1, &slot, pov_mode);
+}
+
+int ffl_sync(ffl_ctx *c) {
+    if (!c) return FFL_ERR_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->s_copy));
+    HIPCHK(c, hipStreamSynchronize(c->s_compute));
+    return FFL_OK;
+}
+
+int ffl_profile_enable(ffl_ctx *c, int on) {
+    if (!c) return FFL_ERR_INVALID;
+    ffl_sync(c);
+    prof_collect(c);
+    c->prof = on != 0;
+    return FFL_OK;
+}
+
+int ffl_profile_read(ffl_ctx *c, int k, int *launches, double *total_ms) {
+    if (!c || k < 0 || k >= FFL_K_COUNT) return FFL_ERR_INVALID;
+    int rc = ffl_sync(c);
+    if (rc) return rc;
+    prof_collect(c);
+    if (launches) *launches = c->prof_launches[k];
+    if (total_ms) *total_ms = c->prof_ms[k];
+    c->prof_launches[k] = 0;
+    c->prof_ms[k] = 0;
+    return FFL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// Shared declarations of the gfx950 kernels behind include/ffl.h.
+//
+// Data layout in HBM (all tightly packed, row-major, sized for level 0 and reused per level):
+//   gray   : uint8  [frame slot][h][w]
+//   I      : float  [unique frame u][lh][lw]                     level image (blur + resize)
+//   R      : float  [unique frame u][5 planes][lh][lw]           polynomial expansion, SoA planes
+//   M      : float  [pair b][5 planes][lh][lw]  (two buffers)    G11,G12,G22,h1,h2 before the box blur
+//   flow   : float2 [pair b][lh][lw]            interleaved (u,v) exactly as cv2 returns it
+// SoA planes (not 20-byte AoS records) so that 64 consecutive lanes read 256 contiguous bytes of
+// one channel; the bilinear gather of R1 in UpdateMatrices then hits mostly-shared cache lines.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define FFL_MAXB 32
+#define FFL_MAXU (2 * FFL_MAXB)
+#define FFL_POLY_N 5
+#define FFL_WIN 15
+#define FFL_WIN_R 7
+
+struct PolyConsts {
+    float g[FFL_POLY_N + 1], xg[FFL_POLY_N + 1], xxg[FFL_POLY_N + 1];
+    double ig11, ig03, ig33, ig55;
+};
+
+struct GaussKernel {
+    float k[32];  // full symmetric kernel, ksize taps, centre at k[ksize/2]
+    int ksize;
+};
+
+struct UTab {  // unique frame u of the batch -> resident frame slot
+    int fslot[FFL_MAXU];
+};
+
+struct PairTab {  // per pair of the batch
+    int u0[FFL_MAXB], u1[FFL_MAXB];  // unique-frame indices of prev / next
+    float *flow[FFL_MAXB];           // flow field being refined at the current level
+    const float *prev[FFL_MAXB];     // coarser-level flow (input of the x2 upsample)
+};
+
+struct Pass1Result {  // written by k_pass1_final, mirrored to pinned host memory
+    int x, y;
+    float div_val;
+    float pad;
+    double mag_sum;   // sum of sqrt(u^2+v^2) over the image (mean = mag_sum / (w*h))
+};
+
+// ---- launchers (each enqueues on `st` and returns; no synchronisation) ----------------------
+void ffl_launch_gray(const uint8_t *bgr, uint8_t *gray, int n_pixels, hipStream_t st);
+void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, int lw, int lh,
+                          GaussKernel gk, float *I, size_t I_stride, hipStream_t st);
+void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stride, size_t plane, int nU, int lw,
+                        int lh, PolyConsts pc, hipStream_t st);
+void ffl_launch_flow_upsample(PairTab pt, int nB, int pw, int ph, int lw, int lh, hipStream_t st);
+void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
+                                size_t M_stride, int lw, int lh, hipStream_t st);
+void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
+                           size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st);
+
+int ffl_pass1_blocks(int w, int h);
+struct ResTab {  // where each pair's pass-1 record goes
+    Pass1Result *r[FFL_MAXB];
+};
+void ffl_launch_pass1(PairTab pt, int nB, int w, int h, int pov_mode, unsigned long long *pkey, double *psum,
+                      ResTab results, hipStream_t st);
+struct RadialTab {
+    const float *flow[FFL_MAXB];
+    double cx[FFL_MAXB], cy[FFL_MAXB];
+};
+void ffl_launch_radial(RadialTab rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st);
+
+// update-matrices body shared by the standalone kernel and the fused blur+solve+update kernel
+__device__ __forceinline__ void ffl_um_pixel(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,
+                                             int w, int h, int x, int y, float dx, float dy, float out[5]) {
+    // border[5] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} as selects (no runtime-indexed array)
+#define FFL_BORDER(i) ((i) < 2 ? 0.14f : 0.4472f)
+    size_t o = (size_t)y * w + x;
+    float fx = x + dx, fy = y + dy;
+    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
+    float r2, r3, r4, r5, r6;
+    fx -= x1;
+    fy -= y1;
+    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
+        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
+        const float *p = R1 + (size_t)y1 * w + x1;
+#define FFL_BIL(c) (a00 * p[(c)*plane] + a01 * p[(c)*plane + 1] + a10 * p[(c)*plane + w] + a11 * p[(c)*plane + w + 1])
+        r2 = FFL_BIL(0);
+        r3 = FFL_BIL(1);
+        r4 = FFL_BIL(2);
+        r5 = FFL_BIL(3);
+        r6 = FFL_BIL(4);
+#undef FFL_BIL
+        r4 = (R0[2 * plane + o] + r4) * 0.5f;
+        r5 = (R0[3 * plane + o] + r5) * 0.5f;
+        r6 = (R0[4 * plane + o] + r6) * 0.25f;
+    } else {
+        r2 = r3 = 0.f;
+        r4 = R0[2 * plane + o];
+        r5 = R0[3 * plane + o];
+        r6 = R0[4 * plane + o] * 0.5f;
+    }
+    r2 = (R0[o] - r2) * 0.5f;
+    r3 = (R0[plane + o] - r3) * 0.5f;
+    r2 += r4 * dy + r6 * dx;
+    r3 += r6 * dy + r5 * dx;
+    if ((unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)) {
+        float scale = (x < 5 ? FFL_BORDER(x) : 1.f) * (x >= w - 5 ? FFL_BORDER(w - x - 1) : 1.f) *
+                      (y < 5 ? FFL_BORDER(y) : 1.f) * (y >= h - 5 ? FFL_BORDER(h - y - 1) : 1.f);
+#undef FFL_BORDER
+        r2 *= scale; r3 *= scale; r4 *= scale; r5 *= scale; r6 *= scale;
+    }
+    out[0] = r4 * r4 + r6 * r6;
+    out[1] = (r4 + r5) * r6;
+    out[2] = r5 * r5 + r6 * r6;
+    out[3] = r4 * r2 + r6 * r3;
+    out[4] = r6 * r2 + r5 * r3;
+}

@@ -1,0 +1,137 @@
+/*
+ * ffl.h -- C ABI of libffl_hip.so: the MI355X (gfx950) implementation of Funscript-Flow's
+ * per-frame-pair motion path.  Plain pointers and sizes only; every entry point returns an int
+ * status (FFL_OK == 0) unless stated otherwise and records a message readable through
+ * ffl_last_error().  There is NO CPU fallback: without a usable HIP device ffl_create() fails.
+ *
+ * What each entry point replaces in the reference (FF = FunscriptFlow.pyw):
+ *
+ *   ffl_device_count        availability probe get_available_backends()            FF:32-63
+ *   ffl_create/ffl_destroy  (no counterpart: the reference's pair kernel is stateless; the context
+ *                           owns the device buffers the CUDA variant allocates per call, FF:984-987)
+ *   ffl_upload_frame        the p0/p1 ndarrays handed to precompute_flow_info       FF:843, 1188-1191
+ *                           (cuda_GpuMat.upload in the CUDA variant, FF:986-987); also does the
+ *                           cv2.cvtColor(..., COLOR_RGB2GRAY) of FF:1082 when given 3 channels
+ *   ffl_flow_pairs          cv2.calcOpticalFlowFarneback(p0,p1,None,0.5,3,15,3,5,1.2,0)  FF:878-879
+ *                           + max_divergence(flow)  FF:884 -> FF:748-758
+ *                           + cv2.cartToPolar / np.mean                             FF:889-890
+ *                           for a whole batch of pairs (Pool.starmap, FF:1190-1191)
+ *   ffl_pass1_result        the dict built at FF:898-907 (pos_center, val_pos, mean_mag, cut)
+ *   ffl_radial              radial_motion_weighted(flow, center, is_cut, pov_mode)  FF:761-785
+ *                           for a batch (ProcessPoolExecutor.submit loop, FF:1232-1236)
+ *   ffl_download_flow       the "flow" entry of that dict (tests / callers that want the array)
+ *   ffl_submit_pair         precompute_wrapper((p0, p1), params)                    FF:1019-1021
+ *
+ * Threading: a context is bound to one device and is internally stream-ordered; calls on one
+ * context must be serialised by the caller (one host thread per GPU is the intended use).
+ */
+#ifndef FFL_H
+#define FFL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FFL_OK 0
+#define FFL_ERR_INVALID 1   /* bad argument (slot out of range, size mismatch, NULL, ...) */
+#define FFL_ERR_HIP 2       /* a HIP runtime call failed; see ffl_last_error */
+#define FFL_ERR_NO_DEVICE 3 /* no usable gfx950 device */
+#define FFL_ERR_STATE 4     /* slot not ready (e.g. result requested before ffl_flow_pairs) */
+
+#define FFL_MAX_BATCH 32    /* pairs per ffl_flow_pairs / ffl_radial call */
+
+typedef struct ffl_ctx ffl_ctx;
+
+/* Number of HIP devices visible to this process (0 when none / no runtime). */
+int ffl_device_count(void);
+
+/* Create a context for frames of exactly width x height on `device`.
+ *   n_frame_slots  gray frames resident on the device (>= 2)
+ *   n_flow_slots   finished flow fields kept resident for pass 2 (the +-6 smoothing window of
+ *                  FF:1203-1214 needs >= 13 + max_batch in a streaming schedule)
+ *   max_batch      pairs processed per ffl_flow_pairs call (1..FFL_MAX_BATCH) */
+int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_slots, int max_batch,
+               ffl_ctx **out);
+void ffl_destroy(ffl_ctx *ctx);
+
+/* Last error text for ctx (or for the failed ffl_create when ctx == NULL). Never NULL. */
+const char *ffl_last_error(const ffl_ctx *ctx);
+
+/* Copy one frame into frame slot `fslot`.  `channels` is 1 (gray uint8, what the reference feeds
+ * Farneback, FF:1082) or 3 (BGR uint8 as cv2.VideoCapture.read returns, FF:178; converted on the
+ * device with OpenCV's 8-bit fixed-point luma).  `stride_bytes` is the row pitch of `data`.
+ * The pixels are copied into pinned staging before the call returns (the caller may reuse its
+ * array); the H2D transfer itself runs on a side stream and overlaps compute already queued. */
+int ffl_upload_frame(ffl_ctx *ctx, int fslot, const uint8_t *data, int width, int height, int channels,
+                     ptrdiff_t stride_bytes);
+
+/* Queue Farneback flow + pass-1 reductions for n pairs: pair i = (frame fslot0[i], frame fslot1[i])
+ * -> flow slot flow_slots[i].  Frames shared between pairs of the batch are expanded once.
+ * pov_mode != 0 skips the divergence argmax (FF:880-882).  Asynchronous. */
+int ffl_flow_pairs(ffl_ctx *ctx, int n, const int *fslot0, const int *fslot1, const int *flow_slots, int pov_mode);
+
+/* Wait for the batch that produced `flow_slot` and return its pass-1 record (FF:898-907):
+ * (x, y) = pos_center, div_val = val_pos, mean_mag, cut = mean_mag > cut_threshold. */
+int ffl_pass1_result(ffl_ctx *ctx, int flow_slot, float cut_threshold, int32_t *x, int32_t *y, float *div_val,
+                     float *mean_mag, int *cut);
+
+/* radial_motion_weighted for n resident flow fields (FF:761-785); out[i] is float64.
+ * is_cut[i] != 0 yields 0.0 without touching the device.  Synchronous. */
+int ffl_radial(ffl_ctx *ctx, int n, const int *flow_slots, const double *cx, const double *cy, const int *is_cut,
+               int pov_mode, double *out);
+
+/* Copy a finished flow field to host memory as (height, width, 2) float32, cv2 layout. */
+int ffl_download_flow(ffl_ctx *ctx, int flow_slot, float *dst);
+
+/* Place a caller-provided (height, width, 2) float32 flow field into `flow_slot` and run the pass-1
+ * reductions on it (lets the post path be checked against reference golden vectors). */
+int ffl_upload_flow(ffl_ctx *ctx, int flow_slot, const float *src, int pov_mode);
+
+/* One-pair convenience: upload prev/next into frame slots 2*slot, 2*slot+1 and queue the pair into
+ * flow slot `slot` (mirrors precompute_wrapper, FF:1019-1021). */
+int ffl_submit_pair(ffl_ctx *ctx, int slot, const uint8_t *prev, const uint8_t *next, int width, int height,
+                    int channels, ptrdiff_t stride_bytes, int pov_mode);
+
+/* Block until everything queued on the context has finished. */
+int ffl_sync(ffl_ctx *ctx);
+
+/* ---- parity-test hooks (used by tests/ only) ------------------------------------------------ */
+
+/* Number of pyramid scales minus one for this context's size (3 for every BASELINE config). */
+int ffl_num_levels(const ffl_ctx *ctx);
+/* Level-k geometry: out_wh[0]=width, out_wh[1]=height. */
+int ffl_level_size(const ffl_ctx *ctx, int level, int *out_wh);
+
+/* Run ONE pair (frame slots f0, f1) and capture the level-`level` intermediates as they stand
+ * before blur iteration `iter` (0: right after the initial UpdateMatrices; 3: end of level).
+ * Any of the output pointers may be NULL.  Planar layouts: R*, M = 5 planes of lh*lw floats;
+ * I* = lh*lw; flow = lh*lw*2 interleaved.  The final full-resolution flow goes to flow slot 0. */
+int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0, float *I1, float *R0, float *R1,
+                   float *M, float *flow);
+
+/* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
+
+/* Enable/disable HIP-event timing of the kernel classes. When enabled every launch of a class is
+ * bracketed by events on the compute stream. */
+int ffl_profile_enable(ffl_ctx *ctx, int on);
+#define FFL_K_GRAY 0
+#define FFL_K_PYRAMID 1
+#define FFL_K_POLYEXP 2
+#define FFL_K_UPSAMPLE 3
+#define FFL_K_UPDATE_MATRICES 4
+#define FFL_K_BLUR_SOLVE 5
+#define FFL_K_PASS1 6
+#define FFL_K_RADIAL 7
+#define FFL_K_COUNT 8
+/* Read and reset the accumulated (launch count, total milliseconds) of one kernel class.
+ * Synchronises the context. */
+int ffl_profile_read(ffl_ctx *ctx, int kernel_class, int *launches, double *total_ms);
+const char *ffl_kernel_name(int kernel_class);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FFL_H */

@@ -1,0 +1,130 @@
+"""GPU parity: every HIP kernel, through the C ABI (include/ffl.h), against the CPU oracle.
+
+Bar (north_star): flow bit-identical to the oracle (same operations in the same order, no FMA
+contraction), argmax pixel index bit-exact, float reductions within 1e-4 relative.
+"""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle as orc
+from funscript_flow_amd import _capi
+from funscript_flow_amd.synth import gray_to_bgr, sine_translate_frames
+
+
+def frames(n, w, h, seed, **kw):
+    return sine_translate_frames(n, w, h, seed=seed, **kw)
+
+
+@pytest.fixture(scope="module")
+def post(golden_dir):
+    return np.load(os.path.join(golden_dir, "post_goldens.npz"))
+
+
+# ------------------------------------------------------------------ per-kernel, per-level parity
+@pytest.mark.parametrize("w,h", [(96, 80), (320, 180), (250, 131)])
+def test_farneback_stages_bit_exact(w, h):
+    fr = frames(2, w, h, seed=21, amp=(3.0, 2.0), period=6)
+    with _capi.Context(w, h, max_batch=1) as ctx:
+        ctx.upload_frame(0, fr[0])
+        ctx.upload_frame(1, fr[1])
+        assert ctx.num_levels() == orc.num_levels(w, h)
+        for level in range(ctx.num_levels(), -1, -1):
+            assert ctx.level_size(level) == orc.level_params(w, h, level)[:2]
+            for it in (0, 2, 3):
+                g = ctx.debug_pair(0, 1, level, it)
+                o = orc.farneback_dbg(fr[0], fr[1], level, it)
+                for key in ("I0", "I1", "R0", "R1", "M", "flow", "out"):
+                    assert np.array_equal(g[key], o[key]), f"{key} differs at level {level} iter {it}: " \
+                        f"max abs {np.abs(g[key] - o[key]).max()}"
+
+
+@pytest.mark.parametrize("w,h,seed", [(640, 360, 0), (256, 256, 3), (200, 120, 8)])
+def test_pair_end_to_end(w, h, seed):
+    fr = frames(3, w, h, seed=seed)
+    with _capi.Context(w, h, max_batch=2) as ctx:
+        for i in range(3):
+            ctx.upload_frame(i, fr[i])
+        ctx.flow_pairs([0, 1], [1, 2], [0, 1])
+        for j in range(2):
+            flow = ctx.download_flow(j)
+            ref = orc.farneback(fr[j], fr[j + 1])
+            assert np.array_equal(flow, ref)
+            x, y, v, mm, cut = ctx.pass1_result(j)
+            ox, oy, ov = orc.max_divergence_np(ref)
+            assert (x, y) == (ox, oy)
+            assert np.float32(v).tobytes() == np.float32(ov).tobytes()
+            assert abs(float(mm) - float(orc.mean_mag_np(ref))) <= 1e-4 * float(orc.mean_mag_np(ref))
+            assert cut == bool(orc.mean_mag_np(ref) > 7)
+            c = (w / 2.0 + 0.3, h / 2.0 - 0.7)
+            for pov in (False, True):
+                got = ctx.radial([j], [c], [False], pov)[0]
+                want = float(orc.radial_np(ref, c, False, pov))
+                scale = max(abs(want), float(np.mean(np.abs(ref))) * max(w, h) * 1e-2)
+                assert abs(got - want) <= 1e-4 * scale
+            assert ctx.radial([j], [c], [True], False)[0] == 0.0
+
+
+def test_bgr_upload_matches_gray_path():
+    w, h = 320, 180
+    fr = frames(2, w, h, seed=5)
+    bgr = gray_to_bgr(fr, gains=(0.9, 1.0, 0.8))
+    with _capi.Context(w, h, max_batch=1) as ctx:
+        ctx.submit_pair(0, bgr[0], bgr[1])
+        flow = ctx.download_flow(0)
+    assert np.array_equal(flow, orc.farneback(orc.bgr2gray(bgr[0]), orc.bgr2gray(bgr[1])))
+
+
+# ------------------------------------------------------------------ post path vs REFERENCE goldens
+@pytest.mark.parametrize("name", ["noise_36x64", "smooth_90x160", "noise_256x256", "ties_40x72", "negfirst_24x40",
+                                  "farneback_180x320", "edge_32x48"])
+def test_post_path_matches_reference_goldens(post, name):
+    flow = post[f"{name}.flow"]
+    h, w, _ = flow.shape
+    with _capi.Context(w, h, max_batch=1, flow_slots=2) as ctx:
+        ctx.upload_flow(0, flow)
+        x, y, v, mm, _ = ctx.pass1_result(0)
+        assert (x, y) == tuple(post[f"{name}.maxdiv"])
+        assert np.float32(v).tobytes() == np.float32(post[f"{name}.maxdiv_val"]).tobytes()
+        ref_mm = float(orc.mean_mag_np(flow))
+        assert abs(float(mm) - ref_mm) <= 1e-4 * max(ref_mm, 1e-30)
+        scale = float(np.mean(np.abs(flow))) * max(h, w)
+        for c, (gw, gp, gc) in zip(post[f"{name}.centers"], post[f"{name}.radial"]):
+            assert abs(ctx.radial([0], [c], [False], False)[0] - gw) <= 1e-4 * max(abs(gw), 1e-6 * scale)
+            assert abs(ctx.radial([0], [c], [False], True)[0] - gp) <= 1e-4 * max(abs(gp), 1e-6 * scale)
+            assert ctx.radial([0], [c], [True], False)[0] == gc == 0.0
+        # POV pass 1: centre of the bottom edge, value 0 (FF:880-882)
+        ctx.upload_flow(1, flow, pov_mode=True)
+        x, y, v, _, _ = ctx.pass1_result(1)
+        assert (x, y, float(v)) == (w // 2, h - 1, 0.0)
+
+
+def test_denormals_and_cut_threshold():
+    """Tiny flow values must not be flushed (the CPU path keeps denormals); cut uses mean_mag > thr."""
+    h, w = 32, 48
+    flow = np.full((h, w, 2), 1e-39, np.float32)
+    flow[10, 20, 0] = 3e-39
+    with _capi.Context(w, h, max_batch=1) as ctx:
+        ctx.upload_flow(0, flow)
+        x, y, v, mm, cut = ctx.pass1_result(0)
+        ox, oy, ov = orc.max_divergence_np(flow)
+        assert (x, y) == (ox, oy) and np.float32(v).tobytes() == np.float32(ov).tobytes()
+        big = np.full((h, w, 2), 6.0, np.float32)   # |flow| = 8.49 > 7 -> cut
+        ctx.upload_flow(0, big)
+        assert ctx.pass1_result(0)[4] is True
+        assert ctx.pass1_result(0, cut_threshold=9.0)[4] is False
+
+
+def test_errors_are_loud():
+    with _capi.Context(64, 64, max_batch=1) as ctx:
+        with pytest.raises(_capi.FFLError):
+            ctx.flow_pairs([0], [1], [0])            # frames never uploaded
+        with pytest.raises(_capi.FFLError):
+            ctx.upload_frame(0, np.zeros((32, 32), np.uint8))  # wrong size
+        with pytest.raises(_capi.FFLError):
+            ctx.pass1_result(0)                       # nothing computed yet
+    with pytest.raises(_capi.FFLError):
+        _capi.Context(8, 8)
