@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- 1080p frame-pairs/s of the HIP pair-motion path (BASELINE.json configs[1]).
+
+A "step" is one pass of the hot path over one batch of B consecutive frame pairs of a synthetic
+1920x1080 sine-translate stream whose gray frames are already resident in HBM: Farneback flow for
+the B pairs (pyramid + PolyExp once per frame, UpdateMatrices, 3 x blur+solve per level, 4 levels),
+pass 1 (|div| argmax + mean magnitude), the +-6 centre smoothing on the host and pass 2 (radial
+weighted mean).  Batches are software-pipelined (batch s+1 is queued before batch s is finalised)
+so the device never waits for the host.
+
+N > 1: one process per GPU (torchrun), every rank streams its own clip (weak scaling, pairs are
+independent); the only exchange is the barrier/MAX around the timed region and a host (gloo) gather
+of the per-pair scalars -- no RCCL collective in the data path.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SIGMA_NK = 1.0 + 0.25 + 0.0625 + 0.015625  # sum of level pixel counts / N for the 4-scale pyramid
+
+
+def alg_bytes_per_batch(N, B, U):
+    """Algorithmic HBM bytes per kernel class for one batch (SURVEY 8d stage graph: every stage
+    reads its inputs once and writes its outputs once, f32 planes)."""
+    s = SIGMA_NK * N
+    return {
+        "k_pyr_level": U * (4 * N + 4 * s),          # u8 full-res read per level + f32 level image write
+        "k_polyexp": U * 24 * s,                      # I 4 -> R 20
+        "k_flow_upsample": B * (10 * (s - N / 64.0) + 8 * N / 64.0),  # coarsest level is a memset
+        "k_update_matrices": B * 68 * s,              # R0 20 + R1 20 + flow 8 -> M 20 (once per level)
+        "k_blur_solve": B * 220 * s,                  # 3 x (M 20 -> flow 8) + 2 fused UpdateMatrices x 68
+        "k_pass1": B * 8 * N,
+        "k_radial": B * 8 * N,
+    }
+
+
+def cpu_baseline(frames, threads, pairs):
+    """Oracle (C restatement, 'port') timed on the host cores: one pair per thread, like the
+    reference's Pool(threads).starmap over pairs (FunscriptFlow.pyw:1190-1191)."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from concurrent.futures import ThreadPoolExecutor
+    import oracle as orc
+    orc.lib()
+    h, w = frames[0].shape
+
+    def one(j):
+        flow, x, y, v, mm = orc.pair_c(frames[j % (len(frames) - 1)], frames[j % (len(frames) - 1) + 1])
+        return orc.radial_c(flow, (w / 2.0, h / 2.0), mm > 7, False)
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(one, range(pairs)))
+    dt = time.perf_counter() - t0
+    return pairs / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
+    ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+
+    import torch  # first: its HIP runtime (same SONAME) is the one libffl_hip.so binds to
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    host_group = None
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        host_group = dist.new_group(backend="gloo")
+
+    from funscript_flow_amd import _capi
+    from funscript_flow_amd.pipeline import SMOOTH_RADIUS
+    from funscript_flow_amd.synth import sine_translate_frames
+
+    W, H, B = args.width, args.height, args.batch
+    N = W * H
+    U = 2 * B if args.independent else B + 1
+    frames = sine_translate_frames(U, W, H, seed=1 if world == 1 else 10 + rank)
+    ctx = _capi.Context(W, H, device=local_rank, frame_slots=U + 1, flow_slots=2 * B, max_batch=B)
+    for i in range(U):
+        ctx.upload_frame(i, frames[i])
+    ctx.sync()
+    if args.independent:
+        f0, f1 = [2 * i for i in range(B)], [2 * i + 1 for i in range(B)]
+    else:
+        f0, f1 = list(range(B)), list(range(1, B + 1))
+
+    results = []
+
+    def enqueue(step):
+        slots = [(step & 1) * B + i for i in range(B)]
+        ctx.flow_pairs(f0, f1, slots)
+        return slots
+
+    def finalize(slots):
+        recs = [ctx.pass1_result(s, 7.0) for s in slots]
+        pos = np.array([[r[0], r[1]] for r in recs], np.float64)
+        cs = [pos[max(0, j - SMOOTH_RADIUS):j + SMOOTH_RADIUS + 1].mean(axis=0) for j in range(B)]
+        dots = ctx.radial(slots, cs, [r[4] for r in recs], False)
+        results.append((recs, dots))
+
+    def run(steps):
+        pending = None
+        for s in range(steps):
+            cur = enqueue(s)
+            if pending is not None:
+                finalize(pending)
+            pending = cur
+        finalize(pending)
+        ctx.sync()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        run(args.warmup)
+    results.clear()
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        # host gather of the per-pair scalars (x, y, cut, dot): the path's only exchange, ~40 B/pair
+        mine = np.array([[r[0], r[1], int(r[4]), d] for recs, dots in results for r, d in zip(recs, dots)], np.float64)
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine, gathered, dst=0, group=host_group)
+        if rank == 0:
+            assert sum(len(g) for g in gathered) == world * args.steps * B
+
+    if rank == 0:
+        pairs = world * args.steps * B
+        alg = alg_bytes_per_batch(N, B, U)
+        dom = max((k for k in alg), key=lambda k: prof[k][1])
+        n_launch, ms = prof[dom]
+        achieved = alg[dom] * args.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("workload") == f"{W}x{H}" and tj.get("batch") == B and tj.get("kernel") == dom:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "1080p frame-pairs/sec" if (W, H) == (1920, 1080) else f"{W}x{H} frame-pairs/sec",
+            "value": pairs / dt,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{W}x{H} synthetic sine-translate frame-pair stream, gray frames resident in HBM",
+                       "pairs_per_step": B, "frames_per_step": U, "levels": 4, "winsize": 15, "iterations": 3,
+                       "poly_n": 5, "parallelism": f"pair-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
+                         "alg_bytes_per_launch": alg[dom] * args.steps / max(n_launch, 1)},
+            "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
+            "whole_path": {"alg_bytes_per_pair": sum(alg.values()) / B,
+                           "achieved_GBps": sum(alg.values()) / B * (pairs / world) / dt / 1e9},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(os.cpu_count() or 1, 16)
+            npairs = args.cpu_pairs or threads
+            v, cdt = cpu_baseline(frames, threads, npairs)
+            out["cpu_baseline"] = {"value": v, "unit": "pairs/s", "cores": threads, "kind": "port",
+                                   "sample": f"{npairs} pairs of the same {W}x{H} stream, one pair per thread, "
+                                             f"C oracle (Farneback + argmax + mean + radial), {cdt:.1f} s wall"}
+        print(json.dumps(out))
+    ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
