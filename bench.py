@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
+    ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows: 8, 16 or 32")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -99,6 +100,8 @@ def main():
     from funscript_flow_amd.pipeline import SMOOTH_RADIUS
     from funscript_flow_amd.synth import sine_translate_frames
 
+    if args.blur_tile_h:
+        _capi.set_option("blur_tile_h", args.blur_tile_h)
     W, H, B = args.width, args.height, args.batch
     N = W * H
     U = 2 * B if args.independent else B + 1

@@ -16,8 +16,8 @@ KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "k_flow_upsample", "k_up
 # every symbol include/ffl.h declares (tests check that the library exports all of them)
 EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "ffl_upload_frame", "ffl_flow_pairs",
            "ffl_pass1_result", "ffl_radial", "ffl_download_flow", "ffl_upload_flow", "ffl_submit_pair", "ffl_sync",
-           "ffl_num_levels", "ffl_level_size", "ffl_debug_pair", "ffl_profile_enable", "ffl_profile_read",
-           "ffl_kernel_name"]
+           "ffl_num_levels", "ffl_level_size", "ffl_debug_pair", "ffl_set_option", "ffl_profile_enable",
+           "ffl_profile_read", "ffl_kernel_name"]
 
 
 class FFLError(RuntimeError):
@@ -59,8 +59,15 @@ def load():
     L.ffl_profile_read.argtypes = [vp, C.c_int, ip, dp]
     L.ffl_kernel_name.argtypes = [C.c_int]
     L.ffl_kernel_name.restype = C.c_char_p
+    L.ffl_set_option.argtypes = [C.c_char_p, C.c_int]
     _lib = L
     return L
+
+
+def set_option(name, value):
+    """Process-wide tuning knob (ffl_set_option); results do not depend on it."""
+    if load().ffl_set_option(name.encode(), int(value)) != FFL_OK:
+        raise FFLError(f"ffl_set_option({name!r}, {value}) rejected")
 
 
 def device_count():

@@ -626,6 +626,16 @@ int ffl_sync(ffl_ctx *c) {
     return FFL_OK;
 }
 
+int ffl_set_option(const char *name, int value) {
+    if (!name) return FFL_ERR_INVALID;
+    if (!strcmp(name, "blur_tile_h")) {
+        if (value != 8 && value != 16) return FFL_ERR_INVALID;
+        ffl_set_blur_tile_h(value);
+        return FFL_OK;
+    }
+    return FFL_ERR_INVALID;
+}
+
 int ffl_profile_enable(ffl_ctx *c, int on) {
     if (!c) return FFL_ERR_INVALID;
     ffl_sync(c);

@@ -64,62 +64,144 @@ __device__ __forceinline__ void ffl_resize_coord(int d, int src, int dst, int &i
     f = fx;
 }
 
-__device__ __forceinline__ float ffl_blur_at(const uint8_t *__restrict__ img, int w, int h, int sx, int sy,
-                                             const GaussKernel &gk) {
-    const int r = gk.ksize >> 1;
-    float acc = 0.f;
-    // vertical combination of horizontally blurred rows, in the oracle's order: centre row first,
-    // then the symmetric pairs j = 1..r
-    for (int j = 0; j <= r; j++) {
-        float hv[2];
-        const int rows[2] = {ffl_reflect101(sy - j, h), ffl_reflect101(sy + j, h)};
-        const int nrow = j == 0 ? 1 : 2;
-        for (int q = 0; q < nrow; q++) {
-            const uint8_t *p = img + (size_t)rows[q] * w;
-            float a = gk.k[r] * (float)p[sx];
-            for (int i = 1; i <= r; i++) {
-                float lo = (float)p[ffl_reflect101(sx - i, w)];
-                float hi = (float)p[ffl_reflect101(sx + i, w)];
-                a = a + gk.k[r + i] * (lo + hi);
-            }
-            hv[q] = a;
-        }
-        if (j == 0) acc = gk.k[r] * hv[0];
-        else acc = acc + gk.k[r + j] * (hv[0] + hv[1]);
-    }
-    return acc;
-}
+// One OW x OH output tile per 256-thread workgroup, three LDS stages:
+//   stage   the full-resolution source window the tile samples (+ blur radius), uint8 -> float,
+//           REFLECT_101 resolved here so the filter loops below are branch-free;
+//   H pass  horizontal blur of every staged row at the (<= 2 per output) sampled columns; lanes run
+//           along rows and the row pitch is odd, so the strided column reads are conflict-free;
+//   V pass  vertical blur at the (<= 2) sampled rows + the two lerps, one output per lane.
+// Samples whose lerp weight is exactly 0 are not evaluated: v*1 + s*0 == v for finite s >= 0.
+struct PyrTile {
+    int OW, OH;   // output tile
+    int SW, SH;   // staged source window (max over tiles), SW odd
+};
 
 __global__ __launch_bounds__(256) void k_pyr_level(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
                                                    int w, int h, int lw, int lh, GaussKernel gk,
-                                                   float *__restrict__ I, size_t I_stride) {
-    int dx = blockIdx.x * 32 + (threadIdx.x & 31);
-    int dy = blockIdx.y * 8 + (threadIdx.x >> 5);
-    int u = blockIdx.z;
-    if (dx >= lw || dy >= lh) return;
+                                                   float *__restrict__ I, size_t I_stride, PyrTile pt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int OW = pt.OW, OH = pt.OH, SW = pt.SW, SH = pt.SH;
+    const int HP = SH | 1;                      // row pitch (in columns) of the H-pass planes: odd
+    float *sSrc = smem;                         // [SH][SW]
+    float *sH = sSrc + SH * SW;                 // [2][OW][HP]  (q, output column, staged row)
+    int *sX0 = reinterpret_cast<int *>(sH + 2 * OW * HP);  // per output column: x0, x1
+    int *sX1 = sX0 + OW;
+    float *sFX = reinterpret_cast<float *>(sX1 + OW);
+    int *sY0 = reinterpret_cast<int *>(sFX + OW);
+    int *sY1 = sY0 + OH;
+    float *sFY = reinterpret_cast<float *>(sY1 + OH);
+
+    const int tid = threadIdx.x, u = blockIdx.z;
+    const int dx0 = blockIdx.x * OW, dy0 = blockIdx.y * OH;
+    const int nx = min(OW, lw - dx0), ny = min(OH, lh - dy0);
+    const int r = gk.ksize >> 1;
     const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
-    int x0, x1, y0, y1;
-    float a1, b1;
-    ffl_resize_coord(dx, w, lw, x0, x1, a1);
-    ffl_resize_coord(dy, h, lh, y0, y1, b1);
-    float a0 = 1.f - a1, b0 = 1.f - b1;
-    // samples with weight exactly 0 are skipped: v*1 + s*0 == v for the finite non-negative s here
-    float v00 = ffl_blur_at(img, w, h, x0, y0, gk);
-    float v01 = a1 != 0.f ? ffl_blur_at(img, w, h, x1, y0, gk) : 0.f;
-    float t0 = v00 * a0 + v01 * a1;
-    float t1 = 0.f;
-    if (b1 != 0.f) {
-        float v10 = ffl_blur_at(img, w, h, x0, y1, gk);
-        float v11 = a1 != 0.f ? ffl_blur_at(img, w, h, x1, y1, gk) : 0.f;
-        t1 = v10 * a0 + v11 * a1;
+
+    if (tid < nx) {
+        int a, b;
+        float f;
+        ffl_resize_coord(dx0 + tid, w, lw, a, b, f);
+        sX0[tid] = a; sX1[tid] = b; sFX[tid] = f;
     }
-    I[(size_t)u * I_stride + (size_t)dy * lw + dx] = t0 * b0 + t1 * b1;
+    if (tid >= 64 && tid - 64 < ny) {
+        int a, b;
+        float f;
+        ffl_resize_coord(dy0 + tid - 64, h, lh, a, b, f);
+        sY0[tid - 64] = a; sY1[tid - 64] = b; sFY[tid - 64] = f;
+    }
+    __syncthreads();
+    const int xs = sX0[0] - r, ys = sY0[0] - r;
+    const int span_w = sX1[nx - 1] + r - xs + 1, span_h = sY1[ny - 1] + r - ys + 1;  // <= SW, SH by construction
+
+    for (int i = tid; i < span_h * span_w; i += 256) {
+        int j = i / span_w, c = i - j * span_w;
+        sSrc[j * SW + c] = (float)img[(size_t)ffl_reflect101(ys + j, h) * w + ffl_reflect101(xs + c, w)];
+    }
+    __syncthreads();
+
+    // H pass: item = (q, d, row j), j fastest across lanes
+    for (int i = tid; i < 2 * nx * span_h; i += 256) {
+        int j = i % span_h, dq = i / span_h;
+        int d = dq % nx, q = dq / nx;
+        float acc = 0.f;
+        if (q == 0 || sFX[d] != 0.f) {
+            const float *p = sSrc + j * SW + ((q ? sX1[d] : sX0[d]) - xs);
+            acc = gk.k[r] * p[0];
+            for (int t = 1; t <= r; t++) acc = acc + gk.k[r + t] * (p[-t] + p[t]);
+        }
+        sH[(q * OW + d) * HP + j] = acc;
+    }
+    __syncthreads();
+
+    // V pass + lerps: one output per lane, dx fastest
+    for (int i = tid; i < nx * ny; i += 256) {
+        int oy = i / nx, ox = i - oy * nx;
+        float a1 = sFX[ox], b1 = sFY[oy], a0 = 1.f - a1, b0 = 1.f - b1;
+        const float *h0 = sH + (0 * OW + ox) * HP, *h1 = sH + (1 * OW + ox) * HP;
+        float t[2] = {0.f, 0.f};
+#pragma unroll
+        for (int qy = 0; qy < 2; qy++) {
+            if (qy == 1 && b1 == 0.f) break;
+            int cy = (qy ? sY1[oy] : sY0[oy]) - ys;
+            float v0 = gk.k[r] * h0[cy];
+            for (int j = 1; j <= r; j++) v0 = v0 + gk.k[r + j] * (h0[cy - j] + h0[cy + j]);
+            float v1 = 0.f;
+            if (a1 != 0.f) {
+                v1 = gk.k[r] * h1[cy];
+                for (int j = 1; j <= r; j++) v1 = v1 + gk.k[r + j] * (h1[cy - j] + h1[cy + j]);
+            }
+            t[qy] = v0 * a0 + v1 * a1;
+        }
+        I[(size_t)u * I_stride + (size_t)(dy0 + oy) * lw + dx0 + ox] = t[0] * b0 + t[1] * b1;
+    }
+}
+
+// host copy of the device coordinate rule, used to size the staged window exactly
+static void host_resize_coord(int d, int src, int dst, int &i0, int &i1) {
+    double scale = (double)src / dst;
+    float fx = (float)((d + 0.5) * scale - 0.5);
+    int sx = (int)floorf(fx);
+    if (sx < 0) sx = 0;
+    if (sx >= src - 1) sx = src - 1;
+    i0 = sx;
+    i1 = sx + 1 < src ? sx + 1 : src - 1;
+}
+
+static int max_span(int src, int dst, int tile, int r) {
+    int best = 0;
+    for (int d0 = 0; d0 < dst; d0 += tile) {
+        int a0, a1, b0, b1;
+        host_resize_coord(d0, src, dst, a0, a1);
+        host_resize_coord(d0 + tile < dst ? d0 + tile - 1 : dst - 1, src, dst, b0, b1);
+        int span = b1 - a0 + 1 + 2 * r;
+        if (span > best) best = span;
+    }
+    return best;
 }
 
 void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, int lw, int lh,
                           GaussKernel gk, float *I, size_t I_stride, hipStream_t st) {
-    dim3 grid((lw + 31) / 32, (lh + 7) / 8, nU);
-    hipLaunchKernelGGL(k_pyr_level, grid, dim3(256), 0, st, gray_base, gray_stride, ut, w, h, lw, lh, gk, I, I_stride);
+    const int r = gk.ksize / 2;
+    // output tile: 64 wide at (near) full resolution, narrower as the decimation factor grows so the
+    // staged window stays within ~56 KB of LDS
+    PyrTile pt;
+    const double sx = (double)w / lw;
+    pt.OW = sx <= 2.5 ? 64 : (sx <= 5 ? 32 : 16);
+    pt.OH = sx <= 1.5 ? 16 : 8;
+    for (;;) {
+        pt.SW = max_span(w, lw, pt.OW, r) | 1;
+        pt.SH = max_span(h, lh, pt.OH, r);
+        size_t bytes = sizeof(float) * ((size_t)pt.SH * pt.SW + 2 * (size_t)pt.OW * (pt.SH | 1)) +
+                       sizeof(int) * 3 * (size_t)(pt.OW + pt.OH);
+        if (bytes <= 60 * 1024 || (pt.OW <= 8 && pt.OH <= 4)) {
+            dim3 grid((lw + pt.OW - 1) / pt.OW, (lh + pt.OH - 1) / pt.OH, nU);
+            hipLaunchKernelGGL(k_pyr_level, grid, dim3(256), bytes, st, gray_base, gray_stride, ut, w, h, lw, lh, gk, I,
+                               I_stride, pt);
+            return;
+        }
+        if (pt.OW > 8) pt.OW >>= 1;
+        else pt.OH >>= 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -262,98 +344,170 @@ void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, P
 }
 
 // ------------------------------------------------------------------------------------------------
-// K5: FarnebackUpdateFlow_Blur: 15x15 box sum of the 5 M planes (double, REPLICATE border, fixed
-// order rows then columns), 2x2 solve in double, flow write, and -- when UPDATE -- the next
-// UpdateMatrices fused on the freshly solved displacement (written to the other M buffer, so
-// neighbouring tiles still read the old M: a Jacobi step, identical to OpenCV's striped update).
+// K5: FarnebackUpdateFlow_Blur: 15x15 box sum of the 5 M planes (double, REPLICATE border, rows
+// then columns, each 15-term sum in the fixed pairwise tree of the oracle's box15()), 2x2 solve in
+// double, flow write, and -- when UPDATE -- the next UpdateMatrices fused on the freshly solved
+// displacement (written to the other M buffer, so neighbouring tiles still read the old M: a Jacobi
+// step, identical to OpenCV's striped in-place update).
 //
-// Per channel: the (TH+14)x(TW+14) float tile is staged in LDS, column sums over 15 rows go to an
-// LDS double buffer, and each lane then adds 15 neighbouring column sums for its pixels.
+// One 64 x TH output tile per 256-thread workgroup:
+//   phase V  390 lanes = 5 channels x 78 tile columns; each lane reads its TH+14 rows straight from
+//            global memory (consecutive lanes = consecutive x: coalesced), forms the TH column sums
+//            with shared s2/s4/s8 partials (8.6 instead of 14 additions per output) and writes them
+//            to LDS as doubles;
+//   phase H  each lane owns 4 consecutive pixels of one row: 9 ds_read_b128 per channel bring the
+//            18 column sums it needs, the same tree gives the 4 window sums;
+//   solve    2x2 system in double, float2 flow store (2 x dwordx4 per lane), fused UpdateMatrices
+//            with dwordx4 R0 loads / M stores.
 // ------------------------------------------------------------------------------------------------
-template <int TW, int TH, bool UPDATE>
+template <int NOUT, typename T>
+__device__ __forceinline__ void ffl_box15_run(const T (&v)[NOUT + 14], double (&out)[NOUT]) {
+    double s2[NOUT + 12], s4[NOUT + 8], s8[NOUT];
+    double dprev = 0.0;
+#pragma unroll
+    for (int t = 0; t < NOUT + 14; t++) {
+        const double d = (double)v[t];  // widened at first use: only a sliding window of partials is live
+        if (t >= 1 && t - 1 < NOUT + 12) s2[t - 1] = dprev + d;
+        if (t >= 3 && t - 3 < NOUT + 8) s4[t - 3] = s2[t - 3] + s2[t - 1];
+        if (t >= 7 && t - 7 < NOUT) s8[t - 7] = s4[t - 7] + s4[t - 3];
+        if (t >= 14) out[t - 14] = ((s8[t - 14] + s4[t - 6]) + s2[t - 2]) + d;
+        dprev = d;
+    }
+}
+
+template <int TH, bool UPDATE>
 __global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout,
                                                     size_t M_stride, const float *__restrict__ R, size_t R_stride,
                                                     size_t plane, PairTab pt, int w, int h) {
-    constexpr int LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
-    constexpr int PPT = TW * TH / 256;  // pixels per thread
-    static_assert(TW == 64 && (TW * TH) % 256 == 0, "tile shape");
-    __shared__ float sT[LH][LW];
-    __shared__ double sS[TH][LW];
+    constexpr int TW = 64, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
+    constexpr int PX = 4;  // consecutive pixels per lane in phase H
+    static_assert(TH == 8 || TH == 16, "one phase-H pass of 256 lanes covers 64 x 16 pixels");
+    // The 5 channels go through LDS in two groups (3 + 2): 3*TH*78 doubles = 30 KB at TH = 16, so
+    // five workgroups fit a CU, and each group's 3*78 / 2*78 column lanes fit one pass of 256 lanes.
+    // double2-typed so that phase H reads with ds_read_b128 (row pitch 624 B = 39 x 16 B).
+    __shared__ double2 sS2[3][TH][LW / 2];
     const int tid = threadIdx.x;
-    const int b = blockIdx.z;
-    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so
+    // linear ids l and l+8 share an L2.  Each XCD walks its own contiguous run of tiles in
+    // column-major order, which keeps vertically adjacent tiles (they share 14 of their 30 input
+    // rows) on one L2 at about the same time instead of re-fetching the halo over the fabric.
+    const int gx_tiles = (w + TW - 1) / TW, gy_tiles = (h + TH - 1) / TH;
+    const int T = gx_tiles * gy_tiles, chunk = (T + 7) >> 3;
+    const int b = blockIdx.x / (chunk * 8);
+    const int l = blockIdx.x - b * (chunk * 8);
+    const int t = (l & 7) * chunk + (l >> 3);
+    if (t >= T) return;
+    const int tile_x = t / gy_tiles, tile_y = t - tile_x * gy_tiles;
+    const int x0 = tile_x * TW, y0 = tile_y * TH;
     const float *Mb = Min + (size_t)b * M_stride;
-    const int lx = tid & 63, lyb = tid >> 6;  // pixel p of this thread: (lx, lyb + 4*p)
 
-    double acc[5][PPT];
+    const int xg = tid & (TW / PX - 1), ty = tid / (TW / PX);  // phase H: 4 pixels (x0+4xg.., y0+ty)
+    double acc[5][PX];
+    double *sS = reinterpret_cast<double *>(&sS2[0][0][0]);
 #pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const float *Mc = Mb + (size_t)c * plane;
-#pragma unroll 1
-        for (int i = tid; i < LH * LW; i += 256) {
-            int ty = i / LW, tx = i - ty * LW;
-            int gy = min(max(y0 + ty - FFL_WIN_R, 0), h - 1), gx = min(max(x0 + tx - FFL_WIN_R, 0), w - 1);
-            sT[ty][tx] = Mc[(size_t)gy * w + gx];
-        }
-        __syncthreads();
-#pragma unroll 1
-        for (int i = tid; i < TH * LW; i += 256) {
-            int ty = i / LW, tx = i - ty * LW;
-            double s = 0.0;
+    for (int g = 0; g < 2; g++) {
+        const int c0 = g * 3, nc = g == 0 ? 3 : 2;
+        // ---- phase V: column sums over 15 rows, one (channel, tile column) per lane ------------
+        if (g) __syncthreads();  // the previous group's sums have been consumed
+        if (tid < nc * LW) {
+            const int cc = tid / LW, tx = tid - cc * LW;
+            const int gx = min(max(x0 + tx - FFL_WIN_R, 0), w - 1);
+            // wave-uniform row base (scalar registers) + one 32-bit per-lane offset for all 30 loads
+            const unsigned lane_off = (unsigned)((c0 + cc) * plane) + (unsigned)gx;
+            float v[LH];
 #pragma unroll
-            for (int j = 0; j < FFL_WIN; j++) s += (double)sT[ty + j][tx];
-            sS[ty][tx] = s;
-        }
-        __syncthreads();
-        {
-            // PPT independent accumulators, each summed in column order j = 0..14; the j loop is kept
-            // rolled so that only PPT LDS reads are in flight (fully unrolled it needs 60 doubles)
-            double s[PPT];
-#pragma unroll
-            for (int p = 0; p < PPT; p++) s[p] = 0.0;
-#pragma unroll 1
-            for (int j = 0; j < FFL_WIN; j++) {
-#pragma unroll
-                for (int p = 0; p < PPT; p++) s[p] += sS[lyb + 4 * p][lx + j];
+            for (int j = 0; j < LH; j++) {
+                const int gy = min(max(y0 + j - FFL_WIN_R, 0), h - 1);
+                const float *row = Mb + (size_t)gy * w;
+                v[j] = row[lane_off];
             }
+            double o[TH];
+            ffl_box15_run<TH>(v, o);
 #pragma unroll
-            for (int p = 0; p < PPT; p++) acc[c][p] = s[p];
+            for (int j = 0; j < TH; j++) sS[(cc * TH + j) * LW + tx] = o[j];
         }
         __syncthreads();
+        // ---- phase H: 4 window sums per lane from 18 column sums (9 x ds_read_b128) -------------
+        if (ty < TH) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                if (cc >= nc) break;
+                double d[PX + 14];
+                const double2 *src = &sS2[cc][ty][xg * (PX / 2)];
+#pragma unroll
+                for (int j = 0; j < (PX + 14) / 2; j++) {
+                    double2 q = src[j];
+                    d[2 * j] = q.x;
+                    d[2 * j + 1] = q.y;
+                }
+                ffl_box15_run<PX>(d, acc[c0 + cc]);
+            }
+        }
     }
 
+    // ---- solve (+ fused UpdateMatrices) ---------------------------------------------------------------
     const double scale = 1.0 / (FFL_WIN * FFL_WIN);
     float2 *flow = reinterpret_cast<float2 *>(pt.flow[b]);
     const float *R0 = R + (size_t)pt.u0[b] * R_stride, *R1 = R + (size_t)pt.u1[b] * R_stride;
+    // The solved displacements are transposed through LDS (aliasing the column-sum buffer) so that
+    // the global phase below runs with lanes along x: 512-B flow rows per wave store, and the
+    // bilinear gathers of R1 by neighbouring lanes fall into neighbouring addresses.
+    __syncthreads();  // every lane has finished reading the column sums
+    float4 *sF4 = reinterpret_cast<float4 *>(&sS2[0][0][0]);  // float2 sF[TH][TW] viewed as float4 pairs
+    if (ty < TH) {
+        float2 f[PX];
 #pragma unroll
-    for (int p = 0; p < PPT; p++) {
-        int x = x0 + lx, y = y0 + lyb + 4 * p;
-        if (x >= w || y >= h) continue;
-        double g11 = acc[0][p] * scale, g12 = acc[1][p] * scale, g22 = acc[2][p] * scale, h1 = acc[3][p] * scale,
-               h2 = acc[4][p] * scale;
-        double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
-        float2 f;
-        f.x = (float)((g11 * h2 - g12 * h1) * idet);
-        f.y = (float)((g22 * h1 - g12 * h2) * idet);
-        flow[(size_t)y * w + x] = f;
+        for (int p = 0; p < PX; p++) {
+            double g11 = acc[0][p] * scale, g12 = acc[1][p] * scale, g22 = acc[2][p] * scale, h1 = acc[3][p] * scale,
+                   h2 = acc[4][p] * scale;
+            double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
+            f[p].x = (float)((g11 * h2 - g12 * h1) * idet);
+            f[p].y = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+        sF4[(ty * TW + xg * PX) / 2] = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
+        sF4[(ty * TW + xg * PX) / 2 + 1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
+    }
+    __syncthreads();
+    const float2 *sF = reinterpret_cast<const float2 *>(sF4);
+    const int lx = tid & 63, x = x0 + lx;
+    if (x >= w) return;
+#pragma unroll
+    for (int k = 0; k < TH / 4; k++) {
+        const int ly = (tid >> 6) + 4 * k, y = y0 + ly;
+        if (y >= h) break;
+        const float2 f = sF[ly * TW + lx];
+        const size_t o = (size_t)y * w + x;
+        flow[o] = f;
         if (UPDATE) {
             float m[5];
             ffl_um_pixel(R0, R1, plane, w, h, x, y, f.x, f.y, m);
-            float *Mo = Mout + (size_t)b * M_stride + (size_t)y * w + x;
+            float *Mo = Mout + (size_t)b * M_stride + o;
 #pragma unroll
             for (int c = 0; c < 5; c++) Mo[c * plane] = m[c];
         }
     }
 }
 
+template <int TH>
+static void launch_blur_solve_t(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
+                                size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st) {
+    const int T = ((lw + 63) / 64) * ((lh + TH - 1) / TH);
+    dim3 grid((unsigned)(((T + 7) / 8) * 8 * nB));
+    if (update)
+        hipLaunchKernelGGL((k_blur_solve<TH, true>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt,
+                           lw, lh);
+    else
+        hipLaunchKernelGGL((k_blur_solve<TH, false>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane,
+                           pt, lw, lh);
+}
+
+static int g_blur_tile_h = 16;
+void ffl_set_blur_tile_h(int th) { g_blur_tile_h = th; }
+
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
                            size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st) {
-    constexpr int TW = 64, TH = 16;
-    dim3 grid((lw + TW - 1) / TW, (lh + TH - 1) / TH, nB);
-    if (update)
-        hipLaunchKernelGGL((k_blur_solve<TW, TH, true>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane,
-                           pt, lw, lh);
-    else
-        hipLaunchKernelGGL((k_blur_solve<TW, TH, false>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride,
-                           plane, pt, lw, lh);
+    switch (g_blur_tile_h) {
+        case 8: launch_blur_solve_t<8>(Min, Mout, M_stride, R, R_stride, plane, pt, nB, lw, lh, update, st); break;
+        default: launch_blur_solve_t<16>(Min, Mout, M_stride, R, R_stride, plane, pt, nB, lw, lh, update, st); break;
+    }
 }

@@ -114,6 +114,10 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 
+/* Process-wide tuning knobs (results do not depend on them):
+ *   "blur_tile_h" = 8 | 16 | 32   rows of the 64-wide k_blur_solve LDS tile (BASELINE configs[2] sweep) */
+int ffl_set_option(const char *name, int value);
+
 /* Enable/disable HIP-event timing of the kernel classes. When enabled every launch of a class is
  * bracketed by events on the compute stream. */
 int ffl_profile_enable(ffl_ctx *ctx, int on);
