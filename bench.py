@@ -25,6 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+DOMINANT = "k_blur_solve"  # per profiles/*_kernel_stats.csv; --profile-all re-derives it live
 SIGMA_NK = 1.0 + 0.25 + 0.0625 + 0.015625  # sum of level pixel counts / N for the 4-scale pyramid
 
 
@@ -74,7 +75,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
-    ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows: 8, 16 or 32")
+    ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows: 8 or 16")
+    ap.add_argument("--no-events", action="store_true", help="diagnostic: no per-kernel HIP events (roofline omitted)")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="HIP events around every kernel class (adds ~0.2 ms/step); default: the dominant kernel only")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -148,7 +152,7 @@ def main():
     if args.warmup > 0:
         run(args.warmup)
     results.clear()
-    ctx.profile_enable(True)
+    ctx.profile_enable(False if args.no_events else (True if args.profile_all else [DOMINANT]))
     barrier()
     t0 = time.perf_counter()
     run(args.steps)

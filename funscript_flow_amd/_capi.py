@@ -55,7 +55,7 @@ def load():
     L.ffl_num_levels.argtypes = [vp]
     L.ffl_level_size.argtypes = [vp, C.c_int, ip]
     L.ffl_debug_pair.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int] + [vp] * 6
-    L.ffl_profile_enable.argtypes = [vp, C.c_int]
+    L.ffl_profile_enable.argtypes = [vp, C.c_uint]
     L.ffl_profile_read.argtypes = [vp, C.c_int, ip, dp]
     L.ffl_kernel_name.argtypes = [C.c_int]
     L.ffl_kernel_name.restype = C.c_char_p
@@ -184,8 +184,15 @@ class Context:
         d["out"] = self.download_flow(0)
         return d
 
-    def profile_enable(self, on=True):
-        self._chk(self.L.ffl_profile_enable(self._h, int(on)))
+    def profile_enable(self, classes=True):
+        """classes: True (all), False/None (off) or an iterable of kernel-class names."""
+        if classes is True:
+            mask = 0xFF
+        elif not classes:
+            mask = 0
+        else:
+            mask = sum(1 << KERNEL_CLASSES.index(c) for c in classes)
+        self._chk(self.L.ffl_profile_enable(self._h, mask))
 
     def profile_read(self):
         out = {}

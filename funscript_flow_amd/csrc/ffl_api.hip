@@ -55,7 +55,7 @@ struct ffl_ctx {
     double *d_psum = nullptr, *d_radial = nullptr, *h_radial = nullptr;
     int p1_blocks = 0;
     // profiling
-    bool prof = false;
+    unsigned prof_mask = 0;   // bit k set: bracket every launch of kernel class k with HIP events
     std::vector<ProfRec> prof_recs;
     int prof_launches[FFL_K_COUNT] = {0};
     double prof_ms[FFL_K_COUNT] = {0};
@@ -185,8 +185,9 @@ struct ProfScope {
     ffl_ctx *c;
     int cls;
     hipEvent_t a = nullptr, b = nullptr;
-    ProfScope(ffl_ctx *c_, int cls_, hipStream_t st) : c(c_), cls(cls_) {
-        if (c->prof) {
+    bool on;
+    ProfScope(ffl_ctx *c_, int cls_, hipStream_t st) : c(c_), cls(cls_), on((c_->prof_mask >> cls_) & 1u) {
+        if (on) {
             hipEventCreate(&a);
             hipEventCreate(&b);
             hipEventRecord(a, st);
@@ -194,7 +195,7 @@ struct ProfScope {
         }
     }
     ~ProfScope() {
-        if (c->prof) {
+        if (on) {
             hipEventRecord(b, stream);
             c->prof_recs.push_back({cls, a, b});
         }
@@ -636,11 +637,11 @@ int ffl_set_option(const char *name, int value) {
     return FFL_ERR_INVALID;
 }
 
-int ffl_profile_enable(ffl_ctx *c, int on) {
+int ffl_profile_enable(ffl_ctx *c, unsigned class_mask) {
     if (!c) return FFL_ERR_INVALID;
     ffl_sync(c);
     prof_collect(c);
-    c->prof = on != 0;
+    c->prof_mask = class_mask;
     return FFL_OK;
 }
 

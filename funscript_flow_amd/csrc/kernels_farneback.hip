@@ -72,10 +72,14 @@ __device__ __forceinline__ void ffl_resize_coord(int d, int src, int dst, int &i
 //   V pass  vertical blur at the (<= 2) sampled rows + the two lerps, one output per lane.
 // Samples whose lerp weight is exactly 0 are not evaluated: v*1 + s*0 == v for finite s >= 0.
 struct PyrTile {
-    int OW, OH;   // output tile
+    int OW, OH;   // output tile (OW a power of two)
     int SW, SH;   // staged source window (max over tiles), SW odd
+    int lgOW;
 };
 
+// R > 0: blur radius known at compile time (taps unrolled, coefficients read once from the kernel
+// arguments into scalar registers); R == 0: runtime radius.
+template <int R>
 __global__ __launch_bounds__(256) void k_pyr_level(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
                                                    int w, int h, int lw, int lh, GaussKernel gk,
                                                    float *__restrict__ I, size_t I_stride, PyrTile pt) {
@@ -94,7 +98,7 @@ __global__ __launch_bounds__(256) void k_pyr_level(const uint8_t *__restrict__ g
     const int tid = threadIdx.x, u = blockIdx.z;
     const int dx0 = blockIdx.x * OW, dy0 = blockIdx.y * OH;
     const int nx = min(OW, lw - dx0), ny = min(OH, lh - dy0);
-    const int r = gk.ksize >> 1;
+    const int r = R > 0 ? R : (gk.ksize >> 1);
     const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
 
     if (tid < nx) {
@@ -113,29 +117,56 @@ __global__ __launch_bounds__(256) void k_pyr_level(const uint8_t *__restrict__ g
     const int xs = sX0[0] - r, ys = sY0[0] - r;
     const int span_w = sX1[nx - 1] + r - xs + 1, span_h = sY1[ny - 1] + r - ys + 1;  // <= SW, SH by construction
 
-    for (int i = tid; i < span_h * span_w; i += 256) {
-        int j = i / span_w, c = i - j * span_w;
-        sSrc[j * SW + c] = (float)img[(size_t)ffl_reflect101(ys + j, h) * w + ffl_reflect101(xs + c, w)];
+    const int lane = tid & 63, wv = tid >> 6;  // all loops below are (wave, lane) nests: no divisions
+    for (int j = wv; j < span_h; j += 4) {
+        const uint8_t *row = img + (size_t)ffl_reflect101(ys + j, h) * w;
+        for (int c = lane; c < span_w; c += 64) sSrc[j * SW + c] = (float)row[ffl_reflect101(xs + c, w)];
     }
     __syncthreads();
 
-    // H pass: item = (q, d, row j), j fastest across lanes
-    for (int i = tid; i < 2 * nx * span_h; i += 256) {
-        int j = i % span_h, dq = i / span_h;
-        int d = dq % nx, q = dq / nx;
-        float acc = 0.f;
-        if (q == 0 || sFX[d] != 0.f) {
-            const float *p = sSrc + j * SW + ((q ? sX1[d] : sX0[d]) - xs);
-            acc = gk.k[r] * p[0];
-            for (int t = 1; t <= r; t++) acc = acc + gk.k[r + t] * (p[-t] + p[t]);
+    // H pass -> sH[q][d][j].  q = 1 (the right lerp neighbour) is needed only when resampling in x.
+    const int nq = (lw != w) ? 2 : 1;
+    if (pt.OW >= 32) {
+        // mild decimation: lanes along output columns (source stride <= 4 floats), waves along rows
+        for (int q = 0; q < nq; q++)
+            for (int d = lane; d < nx; d += 64) {
+                const bool on = q == 0 || sFX[d] != 0.f;
+                const float *p0 = sSrc + ((q ? sX1[d] : sX0[d]) - xs);
+                for (int j = wv; j < span_h; j += 4) {
+                    float acc = 0.f;
+                    if (on) {
+                        const float *p = p0 + j * SW;
+                        acc = gk.k[r] * p[0];
+#pragma unroll
+                        for (int t = 1; t <= r; t++) acc = acc + gk.k[r + t] * (p[-t] + p[t]);
+                    }
+                    sH[(q * OW + d) * HP + j] = acc;
+                }
+            }
+    } else {
+        // strong decimation: lanes along staged rows (odd pitch: conflict-free), waves along (q, d)
+        for (int dq = wv; dq < nq * nx; dq += 4) {
+            const int q = dq >= nx, d = q ? dq - nx : dq;
+            const bool on = q == 0 || sFX[d] != 0.f;
+            const float *p0 = sSrc + ((q ? sX1[d] : sX0[d]) - xs);
+            for (int j = lane; j < span_h; j += 64) {
+                float acc = 0.f;
+                if (on) {
+                    const float *p = p0 + j * SW;
+                    acc = gk.k[r] * p[0];
+#pragma unroll
+                    for (int t = 1; t <= r; t++) acc = acc + gk.k[r + t] * (p[-t] + p[t]);
+                }
+                sH[(q * OW + d) * HP + j] = acc;
+            }
         }
-        sH[(q * OW + d) * HP + j] = acc;
     }
     __syncthreads();
 
-    // V pass + lerps: one output per lane, dx fastest
-    for (int i = tid; i < nx * ny; i += 256) {
-        int oy = i / nx, ox = i - oy * nx;
+    // V pass + lerps: one output per lane, output columns fastest (OW is a power of two)
+    for (int i = tid; i < OW * OH; i += 256) {
+        const int oy = i >> pt.lgOW, ox = i & (OW - 1);
+        if (ox >= nx || oy >= ny) continue;
         float a1 = sFX[ox], b1 = sFY[oy], a0 = 1.f - a1, b0 = 1.f - b1;
         const float *h0 = sH + (0 * OW + ox) * HP, *h1 = sH + (1 * OW + ox) * HP;
         float t[2] = {0.f, 0.f};
@@ -144,10 +175,12 @@ __global__ __launch_bounds__(256) void k_pyr_level(const uint8_t *__restrict__ g
             if (qy == 1 && b1 == 0.f) break;
             int cy = (qy ? sY1[oy] : sY0[oy]) - ys;
             float v0 = gk.k[r] * h0[cy];
+#pragma unroll
             for (int j = 1; j <= r; j++) v0 = v0 + gk.k[r + j] * (h0[cy - j] + h0[cy + j]);
             float v1 = 0.f;
             if (a1 != 0.f) {
                 v1 = gk.k[r] * h1[cy];
+#pragma unroll
                 for (int j = 1; j <= r; j++) v1 = v1 + gk.k[r + j] * (h1[cy - j] + h1[cy + j]);
             }
             t[qy] = v0 * a0 + v1 * a1;
@@ -194,9 +227,17 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut,
         size_t bytes = sizeof(float) * ((size_t)pt.SH * pt.SW + 2 * (size_t)pt.OW * (pt.SH | 1)) +
                        sizeof(int) * 3 * (size_t)(pt.OW + pt.OH);
         if (bytes <= 60 * 1024 || (pt.OW <= 8 && pt.OH <= 4)) {
+            pt.lgOW = 0;
+            while ((1 << pt.lgOW) < pt.OW) pt.lgOW++;
             dim3 grid((lw + pt.OW - 1) / pt.OW, (lh + pt.OH - 1) / pt.OH, nU);
-            hipLaunchKernelGGL(k_pyr_level, grid, dim3(256), bytes, st, gray_base, gray_stride, ut, w, h, lw, lh, gk, I,
-                               I_stride, pt);
+#define FFL_PYR_LAUNCH(RR)                                                                                      \
+    hipLaunchKernelGGL(k_pyr_level<RR>, grid, dim3(256), bytes, st, gray_base, gray_stride, ut, w, h, lw, lh, gk, I, \
+                       I_stride, pt)
+            if (r == 1) FFL_PYR_LAUNCH(1);
+            else if (r == 4) FFL_PYR_LAUNCH(4);
+            else if (r == 9) FFL_PYR_LAUNCH(9);
+            else FFL_PYR_LAUNCH(0);
+#undef FFL_PYR_LAUNCH
             return;
         }
         if (pt.OW > 8) pt.OW >>= 1;

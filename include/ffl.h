@@ -118,9 +118,10 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
  *   "blur_tile_h" = 8 | 16 | 32   rows of the 64-wide k_blur_solve LDS tile (BASELINE configs[2] sweep) */
 int ffl_set_option(const char *name, int value);
 
-/* Enable/disable HIP-event timing of the kernel classes. When enabled every launch of a class is
- * bracketed by events on the compute stream. */
-int ffl_profile_enable(ffl_ctx *ctx, int on);
+/* HIP-event timing of kernel classes: every launch of a class whose bit (1u << FFL_K_*) is set in
+ * class_mask is bracketed by events on the stream it is launched on.  0 switches timing off. */
+int ffl_profile_enable(ffl_ctx *ctx, unsigned class_mask);
+#define FFL_PROFILE_ALL 0xFFu
 #define FFL_K_GRAY 0
 #define FFL_K_PYRAMID 1
 #define FFL_K_POLYEXP 2
