@@ -36,8 +36,9 @@ def alg_bytes_per_batch(N, B, U):
     return {
         "k_pyr_level": U * (4 * N + 4 * s),          # u8 full-res read per level + f32 level image write
         "k_polyexp": U * 24 * s,                      # I 4 -> R 20
-        "k_flow_upsample": B * (10 * (s - N / 64.0) + 8 * N / 64.0),  # coarsest level is a memset
-        "k_update_matrices": B * 68 * s,              # R0 20 + R1 20 + flow 8 -> M 20 (once per level)
+        # flow init (x2 upsample: 2 in at quarter res + 8 out; coarsest level is a memset) is fused into
+        # the per-level UpdateMatrices launch: R0 20 + R1 20 + flow 8 -> M 20
+        "k_update_matrices": B * (68 * s + 10 * (s - N / 64.0) + 8 * N / 64.0),
         "k_blur_solve": B * 220 * s,                  # 3 x (M 20 -> flow 8) + 2 fused UpdateMatrices x 68
         "k_pass1": B * 8 * N,
         "k_radial": B * 8 * N,
@@ -76,6 +77,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
     ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows: 8 or 16")
+    ap.add_argument("--lanes", type=int, default=0, help="compute lanes (co-scheduled batches) per context, default 1")
     ap.add_argument("--no-events", action="store_true", help="diagnostic: no per-kernel HIP events (roofline omitted)")
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP events around every kernel class (adds ~0.2 ms/step); default: the dominant kernel only")
@@ -106,6 +108,11 @@ def main():
 
     if args.blur_tile_h:
         _capi.set_option("blur_tile_h", args.blur_tile_h)
+    # One compute lane by default: kernels of consecutive batches then run back to back, so the
+    # per-launch HIP-event durations behind `roofline` are those of the kernel alone (and agree with
+    # rocprofv3's).  `--lanes 2` (the library's default for production use) co-schedules two batches:
+    # ~+11 % pairs/s at 1080p, but every launch is stretched by its co-runner (profiles/README.md).
+    _capi.set_option("lanes", args.lanes or 1)
     W, H, B = args.width, args.height, args.batch
     N = W * H
     U = 2 * B if args.independent else B + 1
@@ -202,7 +209,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic sine-translate frame-pair stream, gray frames resident in HBM",
                        "pairs_per_step": B, "frames_per_step": U, "levels": 4, "winsize": 15, "iterations": 3,
-                       "poly_n": 5, "parallelism": f"pair-shard x{world}"},
+                       "poly_n": 5, "parallelism": f"pair-shard x{world}", "compute_lanes": args.lanes or 1},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),

@@ -17,6 +17,7 @@
 #include <vector>
 
 static thread_local std::string g_create_error = "";
+static int g_num_lanes = 2;  // compute lanes per context created from now on (ffl_set_option "lanes")
 
 struct ProfRec {
     int cls;
@@ -35,15 +36,25 @@ struct ffl_ctx {
     size_t N = 0;
     LevelGeom geom[8];
     PolyConsts pc;
-    hipStream_t s_copy = nullptr, s_compute = nullptr;
+    hipStream_t s_copy = nullptr, s_post = nullptr;  // uploads (+gray) / pass 2 and flow uploads
+    // Compute lanes: each ffl_flow_pairs batch runs on the next lane (stream + its own work buffers),
+    // so consecutive batches execute concurrently and the device overlaps one batch's f64-bound box
+    // filter with another's bandwidth-bound UpdateMatrices / PolyExp.
+    struct Lane {
+        hipStream_t st = nullptr;
+        float *d_I = nullptr, *d_R = nullptr, *d_M[2] = {nullptr, nullptr}, *d_flowA = nullptr, *d_flowB = nullptr;
+        unsigned long long *d_pkey = nullptr;
+        double *d_psum = nullptr;
+    };
+    std::vector<Lane> lanes;
+    unsigned next_lane = 0;
     // frames
     uint8_t *d_gray = nullptr;        // [n_fslots][N]
     uint8_t *d_bgr = nullptr;         // [n_fslots][3N] staging for 3-channel uploads
     uint8_t *h_stage = nullptr;       // pinned [n_fslots][3N]
-    std::vector<hipEvent_t> ev_uploaded, ev_last_use;
+    std::vector<hipEvent_t> ev_uploaded;
+    std::vector<hipEvent_t> ev_last_use;  // [frame slot * n_lanes + lane]
     std::vector<char> frame_valid;
-    // work buffers
-    float *d_I = nullptr, *d_R = nullptr, *d_M[2] = {nullptr, nullptr}, *d_flowA = nullptr, *d_flowB = nullptr;
     // flow slots
     float *d_flow = nullptr;          // [n_slots][2N]
     Pass1Result *d_res = nullptr;     // [n_slots]
@@ -51,8 +62,8 @@ struct ffl_ctx {
     std::vector<hipEvent_t> ev_slot_done;
     std::vector<char> slot_state;     // 0 empty, 1 queued/ready
     std::vector<char> slot_pov;
-    unsigned long long *d_pkey = nullptr;
-    double *d_psum = nullptr, *d_radial = nullptr, *h_radial = nullptr;
+    double *d_rpsum = nullptr, *d_radial = nullptr, *h_radial = nullptr;  // pass-2 scratch (s_post)
+    unsigned long long *d_ppkey = nullptr;                                 // ffl_upload_flow scratch (s_post)
     int p1_blocks = 0;
     // profiling
     unsigned prof_mask = 0;   // bit k set: bracket every launch of kernel class k with HIP events
@@ -236,19 +247,25 @@ const char *ffl_kernel_name(int k) {
 void ffl_destroy(ffl_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->s_compute) hipStreamSynchronize(c->s_compute);
+    for (auto &L : c->lanes)
+        if (L.st) hipStreamSynchronize(L.st);
+    if (c->s_post) hipStreamSynchronize(c->s_post);
     if (c->s_copy) hipStreamSynchronize(c->s_copy);
     prof_collect(c);
     for (auto e : c->ev_uploaded) hipEventDestroy(e);
     for (auto e : c->ev_last_use) hipEventDestroy(e);
     for (auto e : c->ev_slot_done) hipEventDestroy(e);
     hipFree(c->d_gray); hipFree(c->d_bgr); hipHostFree(c->h_stage);
-    hipFree(c->d_I); hipFree(c->d_R); hipFree(c->d_M[0]); hipFree(c->d_M[1]);
-    hipFree(c->d_flowA); hipFree(c->d_flowB); hipFree(c->d_flow); hipFree(c->d_res);
+    for (auto &L : c->lanes) {
+        hipFree(L.d_I); hipFree(L.d_R); hipFree(L.d_M[0]); hipFree(L.d_M[1]);
+        hipFree(L.d_flowA); hipFree(L.d_flowB); hipFree(L.d_pkey); hipFree(L.d_psum);
+        if (L.st) hipStreamDestroy(L.st);
+    }
+    hipFree(c->d_flow); hipFree(c->d_res);
     hipHostFree(c->h_res);
-    hipFree(c->d_pkey); hipFree(c->d_psum); hipFree(c->d_radial); hipHostFree(c->h_radial);
+    hipFree(c->d_rpsum); hipFree(c->d_ppkey); hipFree(c->d_radial); hipHostFree(c->h_radial);
     if (c->s_copy) hipStreamDestroy(c->s_copy);
-    if (c->s_compute) hipStreamDestroy(c->s_compute);
+    if (c->s_post) hipStreamDestroy(c->s_post);
     delete c;
 }
 
@@ -287,33 +304,37 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     } while (0)
     CCHK(hipSetDevice(device));
     CCHK(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
-    CCHK(hipStreamCreateWithFlags(&c->s_compute, hipStreamNonBlocking));
+    CCHK(hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking));
     const size_t N = c->N;
     const int maxU = 2 * max_batch;
     CCHK(hipMalloc(&c->d_gray, (size_t)n_frame_slots * N));
     CCHK(hipMalloc(&c->d_bgr, (size_t)n_frame_slots * N * 3));
     CCHK(hipHostMalloc(&c->h_stage, (size_t)n_frame_slots * N * 3, hipHostMallocDefault));
-    CCHK(hipMalloc(&c->d_I, sizeof(float) * N * maxU));
-    CCHK(hipMalloc(&c->d_R, sizeof(float) * 5 * N * maxU));
-    CCHK(hipMalloc(&c->d_M[0], sizeof(float) * 5 * N * max_batch));
-    CCHK(hipMalloc(&c->d_M[1], sizeof(float) * 5 * N * max_batch));
-    CCHK(hipMalloc(&c->d_flowA, sizeof(float) * 2 * N * max_batch));
-    CCHK(hipMalloc(&c->d_flowB, sizeof(float) * 2 * N * max_batch));
+    c->p1_blocks = ffl_pass1_blocks(width, height);
+    c->lanes.resize(g_num_lanes);
+    for (auto &L : c->lanes) {
+        CCHK(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
+        CCHK(hipMalloc(&L.d_I, sizeof(float) * N * maxU));
+        CCHK(hipMalloc(&L.d_R, sizeof(float) * 5 * N * maxU));
+        CCHK(hipMalloc(&L.d_M[0], sizeof(float) * 5 * N * max_batch));
+        CCHK(hipMalloc(&L.d_M[1], sizeof(float) * 5 * N * max_batch));
+        CCHK(hipMalloc(&L.d_flowA, sizeof(float) * 2 * N * max_batch));
+        CCHK(hipMalloc(&L.d_flowB, sizeof(float) * 2 * N * max_batch));
+        CCHK(hipMalloc(&L.d_pkey, sizeof(unsigned long long) * c->p1_blocks * FFL_MAXB));
+        CCHK(hipMalloc(&L.d_psum, sizeof(double) * c->p1_blocks * FFL_MAXB));
+    }
     CCHK(hipMalloc(&c->d_flow, sizeof(float) * 2 * N * n_flow_slots));
     CCHK(hipMalloc(&c->d_res, sizeof(Pass1Result) * n_flow_slots));
     CCHK(hipHostMalloc(&c->h_res, sizeof(Pass1Result) * n_flow_slots, hipHostMallocDefault));
-    c->p1_blocks = ffl_pass1_blocks(width, height);
-    CCHK(hipMalloc(&c->d_pkey, sizeof(unsigned long long) * c->p1_blocks * FFL_MAXB));
-    CCHK(hipMalloc(&c->d_psum, sizeof(double) * c->p1_blocks * FFL_MAXB));
+    CCHK(hipMalloc(&c->d_rpsum, sizeof(double) * c->p1_blocks * FFL_MAXB));
+    CCHK(hipMalloc(&c->d_ppkey, sizeof(unsigned long long) * c->p1_blocks));
     CCHK(hipMalloc(&c->d_radial, sizeof(double) * FFL_MAXB));
     CCHK(hipHostMalloc(&c->h_radial, sizeof(double) * FFL_MAXB, hipHostMallocDefault));
     c->ev_uploaded.resize(n_frame_slots);
-    c->ev_last_use.resize(n_frame_slots);
+    c->ev_last_use.resize((size_t)n_frame_slots * g_num_lanes);
     c->frame_valid.assign(n_frame_slots, 0);
-    for (int i = 0; i < n_frame_slots; i++) {
-        CCHK(hipEventCreateWithFlags(&c->ev_uploaded[i], hipEventDisableTiming));
-        CCHK(hipEventCreateWithFlags(&c->ev_last_use[i], hipEventDisableTiming));
-    }
+    for (int i = 0; i < n_frame_slots; i++) CCHK(hipEventCreateWithFlags(&c->ev_uploaded[i], hipEventDisableTiming));
+    for (auto &e : c->ev_last_use) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->ev_slot_done.resize(n_flow_slots);
     c->slot_state.assign(n_flow_slots, 0);
     c->slot_pov.assign(n_flow_slots, 0);
@@ -351,8 +372,9 @@ int ffl_upload_frame(ffl_ctx *c, int fslot, const uint8_t *data, int width, int 
     if ((size_t)stride_bytes == row) memcpy(stage, data, row * height);
     else
         for (int y = 0; y < height; y++) memcpy(stage + (size_t)y * row, data + (ptrdiff_t)y * stride_bytes, row);
-    // the device copy of this slot may still be read by a queued batch
-    HIPCHK(c, hipStreamWaitEvent(c->s_copy, c->ev_last_use[fslot], 0));
+    // the device copy of this slot may still be read by batches queued on any lane
+    for (size_t l = 0; l < c->lanes.size(); l++)
+        HIPCHK(c, hipStreamWaitEvent(c->s_copy, c->ev_last_use[(size_t)fslot * c->lanes.size() + l], 0));
     uint8_t *gray = c->d_gray + (size_t)fslot * N;
     if (channels == 1) {
         HIPCHK(c, hipMemcpyAsync(gray, stage, N, hipMemcpyHostToDevice, c->s_copy));
@@ -372,10 +394,11 @@ struct DebugCapture {
     float *I0, *I1, *R0, *R1, *M, *flow;
 };
 
-// One batch of pairs through the 4-scale Farneback schedule + pass-1 reductions (compute stream).
-static int run_batch(ffl_ctx *c, int n, const int *f0, const int *f1, const int *slots, int pov_mode,
+// One batch of pairs through the 4-scale Farneback schedule + pass-1 reductions, on compute lane `li`.
+static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, const int *slots, int pov_mode,
                      const DebugCapture *cap) {
-    hipStream_t st = c->s_compute;
+    ffl_ctx::Lane &L = c->lanes[li];
+    hipStream_t st = L.st;
     const size_t N = c->N;
     // unique frames of the batch
     UTab ut;
@@ -394,8 +417,11 @@ static int run_batch(ffl_ctx *c, int n, const int *f0, const int *f1, const int 
         pt.u1[i] = uidx(f1[i]);
     }
     for (int i = 0; i < nU; i++) HIPCHK(c, hipStreamWaitEvent(st, c->ev_uploaded[ut.fslot[i]], 0));
+    // a flow slot being recycled may still be read by the batch (other lane) or pass 2 that used it last
+    for (int i = 0; i < n; i++)
+        if (c->slot_state[slots[i]]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_slot_done[slots[i]], 0));
 
-    float *cur = c->d_flowA, *prv = c->d_flowB;
+    float *cur = L.d_flowA, *prv = L.d_flowB;
     int pw = 0, ph = 0;
     for (int k = c->levels; k >= 0; k--) {
         const LevelGeom &g = c->geom[k];
@@ -406,33 +432,30 @@ static int run_batch(ffl_ctx *c, int n, const int *f0, const int *f1, const int 
             pt.flow[i] = (k == 0) ? c->d_flow + (size_t)slots[i] * 2 * N : cur + (size_t)i * 2 * plane;
             pt.prev[i] = prv + (size_t)i * 2 * (size_t)pw * ph;
         }
-        if (pw == 0) {
+        if (pw == 0)
             for (int i = 0; i < n; i++) HIPCHK(c, hipMemsetAsync(pt.flow[i], 0, sizeof(float) * 2 * plane, st));
-        } else {
-            ProfScope ps(c, FFL_K_UPSAMPLE, st);
-            ffl_launch_flow_upsample(pt, n, pw, ph, lw, lh, st);
-        }
         {
             ProfScope ps(c, FFL_K_PYRAMID, st);
-            ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, lw, lh, g.gk, c->d_I, I_stride, st);
+            ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, lw, lh, g.gk, L.d_I, I_stride, st);
         }
         {
             ProfScope ps(c, FFL_K_POLYEXP, st);
-            ffl_launch_polyexp(c->d_I, I_stride, c->d_R, R_stride, plane, nU, lw, lh, c->pc, st);
+            ffl_launch_polyexp(L.d_I, I_stride, L.d_R, R_stride, plane, nU, lw, lh, c->pc, st);
         }
         int mi = 0;
         {
             ProfScope ps(c, FFL_K_UPDATE_MATRICES, st);
-            ffl_launch_update_matrices(c->d_R, R_stride, plane, pt, n, c->d_M[mi], M_stride, lw, lh, st);
+            // the x2 upsample of the coarser level's flow (K3) is fused into this launch
+            ffl_launch_update_matrices(L.d_R, R_stride, plane, pt, n, L.d_M[mi], M_stride, lw, lh, pw, ph, st);
         }
         bool captured = false;
         auto capture = [&]() -> int {
             HIPCHK(c, hipStreamSynchronize(st));
-            if (cap->I0) HIPCHK(c, hipMemcpy(cap->I0, c->d_I + (size_t)pt.u0[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
-            if (cap->I1) HIPCHK(c, hipMemcpy(cap->I1, c->d_I + (size_t)pt.u1[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
-            if (cap->R0) HIPCHK(c, hipMemcpy(cap->R0, c->d_R + (size_t)pt.u0[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
-            if (cap->R1) HIPCHK(c, hipMemcpy(cap->R1, c->d_R + (size_t)pt.u1[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
-            if (cap->M) HIPCHK(c, hipMemcpy(cap->M, c->d_M[mi], sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->I0) HIPCHK(c, hipMemcpy(cap->I0, L.d_I + (size_t)pt.u0[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
+            if (cap->I1) HIPCHK(c, hipMemcpy(cap->I1, L.d_I + (size_t)pt.u1[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
+            if (cap->R0) HIPCHK(c, hipMemcpy(cap->R0, L.d_R + (size_t)pt.u0[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->R1) HIPCHK(c, hipMemcpy(cap->R1, L.d_R + (size_t)pt.u1[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->M) HIPCHK(c, hipMemcpy(cap->M, L.d_M[mi], sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
             if (cap->flow) HIPCHK(c, hipMemcpy(cap->flow, pt.flow[0], sizeof(float) * 2 * plane, hipMemcpyDeviceToHost));
             captured = true;
             return FFL_OK;
@@ -445,7 +468,7 @@ static int run_batch(ffl_ctx *c, int n, const int *f0, const int *f1, const int 
             const int update = it < 2;
             {
                 ProfScope ps(c, FFL_K_BLUR_SOLVE, st);
-                ffl_launch_blur_solve(c->d_M[mi], c->d_M[mi ^ 1], M_stride, c->d_R, R_stride, plane, pt, n, lw, lh,
+                ffl_launch_blur_solve(L.d_M[mi], L.d_M[mi ^ 1], M_stride, L.d_R, R_stride, plane, pt, n, lw, lh,
                                       update, st);
             }
             if (update) mi ^= 1;
@@ -460,7 +483,8 @@ static int run_batch(ffl_ctx *c, int n, const int *f0, const int *f1, const int 
         pw = lw;
         ph = lh;
     }
-    for (int i = 0; i < nU; i++) HIPCHK(c, hipEventRecord(c->ev_last_use[ut.fslot[i]], st));
+    for (int i = 0; i < nU; i++)
+        HIPCHK(c, hipEventRecord(c->ev_last_use[(size_t)ut.fslot[i] * c->lanes.size() + li], st));
 
     // pass 1 on the finished level-0 flows
     ResTab rtab;
@@ -468,7 +492,7 @@ static int run_batch(ffl_ctx *c, int n, const int *f0, const int *f1, const int 
     for (int i = 0; i < n; i++) rtab.r[i] = c->d_res + slots[i];
     {
         ProfScope ps(c, FFL_K_PASS1, st);
-        ffl_launch_pass1(pt, n, c->w, c->h, pov_mode, c->d_pkey, c->d_psum, rtab, st);
+        ffl_launch_pass1(pt, n, c->w, c->h, pov_mode, L.d_pkey, L.d_psum, rtab, st);
     }
     for (int i = 0; i < n; i++) {
         HIPCHK(c, hipMemcpyAsync(c->h_res + slots[i], c->d_res + slots[i], sizeof(Pass1Result), hipMemcpyDeviceToHost, st));
@@ -502,7 +526,8 @@ int ffl_flow_pairs(ffl_ctx *c, int n, const int *fslot0, const int *fslot1, cons
     int rc = check_pairs(c, n, fslot0, fslot1, flow_slots);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
-    return run_batch(c, n, fslot0, fslot1, flow_slots, pov_mode, nullptr);
+    const int li = (int)(c->next_lane++ % c->lanes.size());
+    return run_batch(c, li, n, fslot0, fslot1, flow_slots, pov_mode, nullptr);
 }
 
 int ffl_debug_pair(ffl_ctx *c, int f0, int f1, int level, int iter, float *I0, float *I1, float *R0, float *R1,
@@ -514,9 +539,9 @@ int ffl_debug_pair(ffl_ctx *c, int f0, int f1, int level, int iter, float *I0, f
     if (level < 0 || level > c->levels || iter < 0 || iter > 3) return set_err(c, FFL_ERR_INVALID, "bad level/iter");
     HIPCHK(c, hipSetDevice(c->device));
     DebugCapture cap = {level, iter, I0, I1, R0, R1, M, flow};
-    rc = run_batch(c, 1, &f0, &f1, &slot, 0, &cap);
+    rc = run_batch(c, 0, 1, &f0, &f1, &slot, 0, &cap);
     if (rc) return rc;
-    HIPCHK(c, hipStreamSynchronize(c->s_compute));
+    HIPCHK(c, hipStreamSynchronize(c->lanes[0].st));
     return FFL_OK;
 }
 
@@ -553,16 +578,17 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
             out[i] = 0.0;
             continue;
         }
+        HIPCHK(c, hipStreamWaitEvent(c->s_post, c->ev_slot_done[slots[i]], 0));
         rt.flow[m] = c->d_flow + (size_t)slots[i] * 2 * c->N;
         rt.cx[m] = cx[i];
         rt.cy[m] = cy[i];
         map[m++] = i;
     }
     if (m == 0) return FFL_OK;
-    hipStream_t st = c->s_compute;
+    hipStream_t st = c->s_post;
     {
         ProfScope ps(c, FFL_K_RADIAL, st);
-        ffl_launch_radial(rt, m, c->w, c->h, pov_mode, c->d_psum, c->d_radial, st);
+        ffl_launch_radial(rt, m, c->w, c->h, pov_mode, c->d_rpsum, c->d_radial, st);
     }
     HIPCHK(c, hipMemcpyAsync(c->h_radial, c->d_radial, sizeof(double) * m, hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipStreamSynchronize(st));
@@ -585,7 +611,8 @@ int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
     if (!c) return FFL_ERR_INVALID;
     if (slot < 0 || slot >= c->n_slots || !src) return set_err(c, FFL_ERR_INVALID, "ffl_upload_flow: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    hipStream_t st = c->s_compute;
+    hipStream_t st = c->s_post;
+    if (c->slot_state[slot]) HIPCHK(c, hipEventSynchronize(c->ev_slot_done[slot]));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipMemcpy(c->d_flow + (size_t)slot * 2 * c->N, src, sizeof(float) * 2 * c->N, hipMemcpyHostToDevice));
     PairTab pt;
@@ -596,7 +623,7 @@ int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
     rtab.r[0] = c->d_res + slot;
     {
         ProfScope ps(c, FFL_K_PASS1, st);
-        ffl_launch_pass1(pt, 1, c->w, c->h, pov_mode, c->d_pkey, c->d_psum, rtab, st);
+        ffl_launch_pass1(pt, 1, c->w, c->h, pov_mode, c->d_ppkey, c->d_rpsum, rtab, st);
     }
     HIPCHK(c, hipMemcpyAsync(c->h_res + slot, c->d_res + slot, sizeof(Pass1Result), hipMemcpyDeviceToHost, st));
     HIPCHK(c, hipEventRecord(c->ev_slot_done[slot], st));
@@ -623,7 +650,8 @@ int ffl_sync(ffl_ctx *c) {
     if (!c) return FFL_ERR_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->s_copy));
-    HIPCHK(c, hipStreamSynchronize(c->s_compute));
+    for (auto &L : c->lanes) HIPCHK(c, hipStreamSynchronize(L.st));
+    HIPCHK(c, hipStreamSynchronize(c->s_post));
     return FFL_OK;
 }
 
@@ -632,6 +660,11 @@ int ffl_set_option(const char *name, int value) {
     if (!strcmp(name, "blur_tile_h")) {
         if (value != 8 && value != 16) return FFL_ERR_INVALID;
         ffl_set_blur_tile_h(value);
+        return FFL_OK;
+    }
+    if (!strcmp(name, "lanes")) {  // compute lanes of contexts created afterwards
+        if (value < 1 || value > 4) return FFL_ERR_INVALID;
+        g_num_lanes = value;
         return FFL_OK;
     }
     return FFL_ERR_INVALID;

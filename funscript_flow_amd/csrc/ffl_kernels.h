@@ -52,8 +52,9 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut,
 void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stride, size_t plane, int nU, int lw,
                         int lh, PolyConsts pc, hipStream_t st);
 void ffl_launch_flow_upsample(PairTab pt, int nB, int pw, int ph, int lw, int lh, hipStream_t st);
+// pw > 0: also produce the level's initial flow = x2 bilinear upsample of pt.prev (pw x ph) into pt.flow
 void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
-                                size_t M_stride, int lw, int lh, hipStream_t st);
+                                size_t M_stride, int lw, int lh, int pw, int ph, hipStream_t st);
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
                            size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st);
 
@@ -70,6 +71,31 @@ struct RadialTab {
     double cx[FFL_MAXB], cy[FFL_MAXB];
 };
 void ffl_launch_radial(RadialTab rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st);
+
+// XCD-aware tile order (speed only, never correctness).  Workgroups are dealt round-robin over the 8
+// XCDs, so linear ids l and l+8 share an L2.  Each XCD gets one contiguous run of tiles, walked in
+// panels of FFL_PANEL_W tile columns, row-major inside a panel: a tile's left/right neighbour runs
+// right next to it in time and its upper/lower neighbour FFL_PANEL_W tiles later, all on the same L2,
+// so stencil halos and gather neighbourhoods are re-read from L2 instead of over the fabric.
+// Grid: ffl_tile_grid(tiles_x, tiles_y, nB) workgroups, 1-D.  Returns false for padding workgroups.
+#define FFL_PANEL_W 4
+static inline unsigned ffl_tile_grid(int tiles_x, int tiles_y, int nB) {
+    const int T = tiles_x * tiles_y;
+    return (unsigned)(((T + 7) / 8) * 8 * nB);
+}
+__device__ __forceinline__ bool ffl_tile_coord(int tiles_x, int tiles_y, int &b, int &tile_x, int &tile_y) {
+    const int T = tiles_x * tiles_y, chunk = (T + 7) >> 3;
+    b = blockIdx.x / (chunk * 8);
+    const int l = blockIdx.x - b * (chunk * 8);
+    const int t = (l & 7) * chunk + (l >> 3);
+    if (t >= T) return false;
+    const int per_panel = FFL_PANEL_W * tiles_y;
+    const int panel = t / per_panel, within = t - panel * per_panel;
+    const int pw = min(FFL_PANEL_W, tiles_x - panel * FFL_PANEL_W);  // the last panel may be narrower
+    tile_y = within / pw;
+    tile_x = panel * FFL_PANEL_W + (within - tile_y * pw);
+    return true;
+}
 
 // update-matrices body shared by the standalone kernel and the fused blur+solve+update kernel
 __device__ __forceinline__ void ffl_um_pixel(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,

@@ -360,28 +360,67 @@ void ffl_launch_flow_upsample(PairTab pt, int nB, int pw, int ph, int lw, int lh
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: FarnebackUpdateMatrices (standalone; runs once per level before the first blur iteration)
+// K4: FarnebackUpdateMatrices (standalone; runs once per level before the first blur iteration).
+// With UPSAMPLE the level's initial flow (K3: x2 bilinear upsample of the coarser level's result) is
+// produced here as well, written once and used from registers.  64x16 tiles in XCD-aware panel
+// order: the R1 rows y1, y1+1 gathered by vertically adjacent tiles are re-read from L2.
 // ------------------------------------------------------------------------------------------------
+template <bool UPSAMPLE>
 __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R, size_t R_stride, size_t plane,
                                                          PairTab pt, float *__restrict__ M, size_t M_stride, int w,
-                                                         int h) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    int b = blockIdx.z;
-    if (x >= w || y >= h) return;
+                                                         int h, int pw, int ph) {
+    int b, tile_x, tile_y;
+    if (!ffl_tile_coord((w + 63) / 64, (h + 15) / 16, b, tile_x, tile_y)) return;
+    const int x = tile_x * 64 + (threadIdx.x & 63);
+    if (x >= w) return;
     const float *R0 = R + (size_t)pt.u0[b] * R_stride, *R1 = R + (size_t)pt.u1[b] * R_stride;
-    float2 f = reinterpret_cast<const float2 *>(pt.flow[b])[(size_t)y * w + x];
-    float m[5];
-    ffl_um_pixel(R0, R1, plane, w, h, x, y, f.x, f.y, m);
-    float *Mo = M + (size_t)b * M_stride + (size_t)y * w + x;
+    float2 *flow = reinterpret_cast<float2 *>(pt.flow[b]);
+    const float2 *prev = reinterpret_cast<const float2 *>(pt.prev[b]);
+    int x0 = 0, x1 = 0;
+    float a1 = 0.f;
+    if (UPSAMPLE) ffl_resize_coord(x, pw, w, x0, x1, a1);
 #pragma unroll
-    for (int c = 0; c < 5; c++) Mo[c * plane] = m[c];
+    for (int k = 0; k < 4; k++) {
+        const int y = tile_y * 16 + (threadIdx.x >> 6) + 4 * k;
+        if (y >= h) break;
+        const size_t o = (size_t)y * w + x;
+        float2 f;
+        if (UPSAMPLE) {
+            int y0, y1;
+            float b1;
+            ffl_resize_coord(y, ph, h, y0, y1, b1);
+            const float a0 = 1.f - a1, b0 = 1.f - b1;
+            const float2 p00 = prev[(size_t)y0 * pw + x0], p01 = prev[(size_t)y0 * pw + x1];
+            const float2 p10 = prev[(size_t)y1 * pw + x0], p11 = prev[(size_t)y1 * pw + x1];
+            {
+                float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
+                f.x = (t0 * b0 + t1 * b1) * 2.0f;
+            }
+            {
+                float t0 = p00.y * a0 + p01.y * a1, t1 = p10.y * a0 + p11.y * a1;
+                f.y = (t0 * b0 + t1 * b1) * 2.0f;
+            }
+            flow[o] = f;
+        } else {
+            f = flow[o];
+        }
+        float m[5];
+        ffl_um_pixel(R0, R1, plane, w, h, x, y, f.x, f.y, m);
+        float *Mo = M + (size_t)b * M_stride + o;
+#pragma unroll
+        for (int c = 0; c < 5; c++) Mo[c * plane] = m[c];
+    }
 }
 
 void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
-                                size_t M_stride, int lw, int lh, hipStream_t st) {
-    dim3 grid((lw + 63) / 64, (lh + 3) / 4, nB);
-    hipLaunchKernelGGL(k_update_matrices, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh);
+                                size_t M_stride, int lw, int lh, int pw, int ph, hipStream_t st) {
+    dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + 15) / 16, nB));
+    if (pw > 0)
+        hipLaunchKernelGGL(k_update_matrices<true>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
+                           pw, ph);
+    else
+        hipLaunchKernelGGL(k_update_matrices<false>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
+                           0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -401,6 +440,10 @@ void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, P
 //   solve    2x2 system in double, float2 flow store (2 x dwordx4 per lane), fused UpdateMatrices
 //            with dwordx4 R0 loads / M stores.
 // ------------------------------------------------------------------------------------------------
+#ifndef FFL_K5_WAVES
+#define FFL_K5_WAVES 4  // waves per SIMD the register allocator must leave room for (= workgroups per CU)
+#endif
+
 template <int NOUT, typename T>
 __device__ __forceinline__ void ffl_box15_run(const T (&v)[NOUT + 14], double (&out)[NOUT]) {
     double s2[NOUT + 12], s4[NOUT + 8], s8[NOUT];
@@ -417,7 +460,7 @@ __device__ __forceinline__ void ffl_box15_run(const T (&v)[NOUT + 14], double (&
 }
 
 template <int TH, bool UPDATE>
-__global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout,
+__global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout,
                                                     size_t M_stride, const float *__restrict__ R, size_t R_stride,
                                                     size_t plane, PairTab pt, int w, int h) {
     constexpr int TW = 64, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
@@ -428,17 +471,8 @@ __global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ Mi
     // double2-typed so that phase H reads with ds_read_b128 (row pitch 624 B = 39 x 16 B).
     __shared__ double2 sS2[3][TH][LW / 2];
     const int tid = threadIdx.x;
-    // XCD-aware tile order (speed only): workgroups are dealt round-robin over the 8 XCDs, so
-    // linear ids l and l+8 share an L2.  Each XCD walks its own contiguous run of tiles in
-    // column-major order, which keeps vertically adjacent tiles (they share 14 of their 30 input
-    // rows) on one L2 at about the same time instead of re-fetching the halo over the fabric.
-    const int gx_tiles = (w + TW - 1) / TW, gy_tiles = (h + TH - 1) / TH;
-    const int T = gx_tiles * gy_tiles, chunk = (T + 7) >> 3;
-    const int b = blockIdx.x / (chunk * 8);
-    const int l = blockIdx.x - b * (chunk * 8);
-    const int t = (l & 7) * chunk + (l >> 3);
-    if (t >= T) return;
-    const int tile_x = t / gy_tiles, tile_y = t - tile_x * gy_tiles;
+    int b, tile_x, tile_y;  // XCD-aware panel order, see ffl_tile_coord
+    if (!ffl_tile_coord((w + TW - 1) / TW, (h + TH - 1) / TH, b, tile_x, tile_y)) return;
     const int x0 = tile_x * TW, y0 = tile_y * TH;
     const float *Mb = Min + (size_t)b * M_stride;
 
@@ -532,8 +566,7 @@ __global__ __launch_bounds__(256) void k_blur_solve(const float *__restrict__ Mi
 template <int TH>
 static void launch_blur_solve_t(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
                                 size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st) {
-    const int T = ((lw + 63) / 64) * ((lh + TH - 1) / TH);
-    dim3 grid((unsigned)(((T + 7) / 8) * 8 * nB));
+    dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + TH - 1) / TH, nB));
     if (update)
         hipLaunchKernelGGL((k_blur_solve<TH, true>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt,
                            lw, lh);
