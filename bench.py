@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
     ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows: 8 or 16")
     ap.add_argument("--lanes", type=int, default=0, help="compute lanes (co-scheduled batches) per context, default 1")
+    ap.add_argument("--rehearse-gloo", action="store_true",
+                    help="N>1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the process group is gloo")
     ap.add_argument("--no-events", action="store_true", help="diagnostic: no per-kernel HIP events (roofline omitted)")
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP events around every kernel class (adds ~0.2 ms/step); default: the dominant kernel only")
@@ -95,12 +97,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     host_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        host_group = dist.new_group(backend="gloo")
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+            host_group = dist.group.WORLD
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            host_group = dist.new_group(backend="gloo")
 
     from funscript_flow_amd import _capi
     from funscript_flow_amd.pipeline import SMOOTH_RADIUS
@@ -169,7 +177,7 @@ def main():
     ctx.profile_enable(False)
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # host gather of the per-pair scalars (x, y, cut, dot): the path's only exchange, ~40 B/pair
