@@ -18,6 +18,7 @@
 
 static thread_local std::string g_create_error = "";
 static int g_num_lanes = 2;  // compute lanes per context created from now on (ffl_set_option "lanes")
+static bool g_run_ahead = false;  // frame-only kernels on a side stream (ffl_set_option "run_ahead"): +8 % with 1 lane, a loss with 2
 
 struct ProfRec {
     int cls;
@@ -42,6 +43,12 @@ struct ffl_ctx {
     // filter with another's bandwidth-bound UpdateMatrices / PolyExp.
     struct Lane {
         hipStream_t st = nullptr;
+        // Frame-only work (pyramid + PolyExp of every level) runs ahead on `st_aux` and overlaps the
+        // flow chain of the coarser levels, whose small grids leave most of the device idle; the
+        // chain on `st` waits for ev_R[k] before touching level k.  R holds all levels at once.
+        hipStream_t st_aux = nullptr;
+        hipEvent_t ev_R[8] = {nullptr}, ev_done = nullptr;
+        size_t r_off[8] = {0};  // float offset of level k inside d_R
         float *d_I = nullptr, *d_R = nullptr, *d_M[2] = {nullptr, nullptr}, *d_flowA = nullptr, *d_flowB = nullptr;
         unsigned long long *d_pkey = nullptr;
         double *d_psum = nullptr;
@@ -259,6 +266,10 @@ void ffl_destroy(ffl_ctx *c) {
     for (auto &L : c->lanes) {
         hipFree(L.d_I); hipFree(L.d_R); hipFree(L.d_M[0]); hipFree(L.d_M[1]);
         hipFree(L.d_flowA); hipFree(L.d_flowB); hipFree(L.d_pkey); hipFree(L.d_psum);
+        for (auto e : L.ev_R)
+            if (e) hipEventDestroy(e);
+        if (L.ev_done) hipEventDestroy(L.ev_done);
+        if (L.st_aux) hipStreamDestroy(L.st_aux);
         if (L.st) hipStreamDestroy(L.st);
     }
     hipFree(c->d_flow); hipFree(c->d_res);
@@ -315,7 +326,15 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     for (auto &L : c->lanes) {
         CCHK(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
         CCHK(hipMalloc(&L.d_I, sizeof(float) * N * maxU));
-        CCHK(hipMalloc(&L.d_R, sizeof(float) * 5 * N * maxU));
+        CCHK(hipStreamCreateWithFlags(&L.st_aux, hipStreamNonBlocking));
+        CCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+        size_t r_total = 0;
+        for (int k = 0; k <= c->levels; k++) {
+            CCHK(hipEventCreateWithFlags(&L.ev_R[k], hipEventDisableTiming));
+            L.r_off[k] = r_total;
+            r_total += (size_t)5 * c->geom[k].lw * c->geom[k].lh * maxU;
+        }
+        CCHK(hipMalloc(&L.d_R, sizeof(float) * r_total));
         CCHK(hipMalloc(&L.d_M[0], sizeof(float) * 5 * N * max_batch));
         CCHK(hipMalloc(&L.d_M[1], sizeof(float) * 5 * N * max_batch));
         CCHK(hipMalloc(&L.d_flowA, sizeof(float) * 2 * N * max_batch));
@@ -421,6 +440,30 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     for (int i = 0; i < n; i++)
         if (c->slot_state[slots[i]]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_slot_done[slots[i]], 0));
 
+    // frame-only expansion of level k (level image + PolyExp of the nU unique frames) on stream s
+    auto expand_level = [&](int k, hipStream_t s) {
+        const LevelGeom &g = c->geom[k];
+        const size_t plane = (size_t)g.lw * g.lh;
+        {
+            ProfScope ps(c, FFL_K_PYRAMID, s);
+            ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, g.lw, g.lh, g.gk, L.d_I, plane, s);
+        }
+        {
+            ProfScope ps(c, FFL_K_POLYEXP, s);
+            ffl_launch_polyexp(L.d_I, plane, L.d_R + L.r_off[k], 5 * plane, plane, nU, g.lw, g.lh, c->pc, s);
+        }
+    };
+    const bool run_ahead = cap == nullptr && g_run_ahead;
+    if (run_ahead) {
+        hipStream_t sa = L.st_aux;
+        HIPCHK(c, hipStreamWaitEvent(sa, L.ev_done, 0));  // the lane's previous batch has finished with R
+        for (int i = 0; i < nU; i++) HIPCHK(c, hipStreamWaitEvent(sa, c->ev_uploaded[ut.fslot[i]], 0));
+        for (int k = c->levels; k >= 0; k--) {
+            expand_level(k, sa);
+            HIPCHK(c, hipEventRecord(L.ev_R[k], sa));
+        }
+    }
+
     float *cur = L.d_flowA, *prv = L.d_flowB;
     int pw = 0, ph = 0;
     for (int k = c->levels; k >= 0; k--) {
@@ -428,33 +471,28 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         const int lw = g.lw, lh = g.lh;
         const size_t plane = (size_t)lw * lh;
         const size_t I_stride = plane, R_stride = 5 * plane, M_stride = 5 * plane;
+        float *Rk = L.d_R + L.r_off[k];
         for (int i = 0; i < n; i++) {
             pt.flow[i] = (k == 0) ? c->d_flow + (size_t)slots[i] * 2 * N : cur + (size_t)i * 2 * plane;
             pt.prev[i] = prv + (size_t)i * 2 * (size_t)pw * ph;
         }
         if (pw == 0)
             for (int i = 0; i < n; i++) HIPCHK(c, hipMemsetAsync(pt.flow[i], 0, sizeof(float) * 2 * plane, st));
-        {
-            ProfScope ps(c, FFL_K_PYRAMID, st);
-            ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, lw, lh, g.gk, L.d_I, I_stride, st);
-        }
-        {
-            ProfScope ps(c, FFL_K_POLYEXP, st);
-            ffl_launch_polyexp(L.d_I, I_stride, L.d_R, R_stride, plane, nU, lw, lh, c->pc, st);
-        }
+        if (run_ahead) HIPCHK(c, hipStreamWaitEvent(st, L.ev_R[k], 0));
+        else expand_level(k, st);
         int mi = 0;
         {
             ProfScope ps(c, FFL_K_UPDATE_MATRICES, st);
             // the x2 upsample of the coarser level's flow (K3) is fused into this launch
-            ffl_launch_update_matrices(L.d_R, R_stride, plane, pt, n, L.d_M[mi], M_stride, lw, lh, pw, ph, st);
+            ffl_launch_update_matrices(Rk, R_stride, plane, pt, n, L.d_M[mi], M_stride, lw, lh, pw, ph, st);
         }
         bool captured = false;
         auto capture = [&]() -> int {
             HIPCHK(c, hipStreamSynchronize(st));
             if (cap->I0) HIPCHK(c, hipMemcpy(cap->I0, L.d_I + (size_t)pt.u0[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
             if (cap->I1) HIPCHK(c, hipMemcpy(cap->I1, L.d_I + (size_t)pt.u1[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
-            if (cap->R0) HIPCHK(c, hipMemcpy(cap->R0, L.d_R + (size_t)pt.u0[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
-            if (cap->R1) HIPCHK(c, hipMemcpy(cap->R1, L.d_R + (size_t)pt.u1[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->R0) HIPCHK(c, hipMemcpy(cap->R0, Rk + (size_t)pt.u0[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->R1) HIPCHK(c, hipMemcpy(cap->R1, Rk + (size_t)pt.u1[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
             if (cap->M) HIPCHK(c, hipMemcpy(cap->M, L.d_M[mi], sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
             if (cap->flow) HIPCHK(c, hipMemcpy(cap->flow, pt.flow[0], sizeof(float) * 2 * plane, hipMemcpyDeviceToHost));
             captured = true;
@@ -468,7 +506,7 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
             const int update = it < 2;
             {
                 ProfScope ps(c, FFL_K_BLUR_SOLVE, st);
-                ffl_launch_blur_solve(L.d_M[mi], L.d_M[mi ^ 1], M_stride, L.d_R, R_stride, plane, pt, n, lw, lh,
+                ffl_launch_blur_solve(L.d_M[mi], L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, n, lw, lh,
                                       update, st);
             }
             if (update) mi ^= 1;
@@ -485,6 +523,7 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     }
     for (int i = 0; i < nU; i++)
         HIPCHK(c, hipEventRecord(c->ev_last_use[(size_t)ut.fslot[i] * c->lanes.size() + li], st));
+    HIPCHK(c, hipEventRecord(L.ev_done, st));  // R / I of this lane may be overwritten from here on
 
     // pass 1 on the finished level-0 flows
     ResTab rtab;
@@ -665,6 +704,10 @@ int ffl_set_option(const char *name, int value) {
     if (!strcmp(name, "lanes")) {  // compute lanes of contexts created afterwards
         if (value < 1 || value > 4) return FFL_ERR_INVALID;
         g_num_lanes = value;
+        return FFL_OK;
+    }
+    if (!strcmp(name, "run_ahead")) {  // 1: pyramid + PolyExp of all levels on the lane's side stream
+        g_run_ahead = value != 0;
         return FFL_OK;
     }
     return FFL_ERR_INVALID;
