@@ -51,7 +51,6 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut,
                           GaussKernel gk, float *I, size_t I_stride, hipStream_t st);
 void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stride, size_t plane, int nU, int lw,
                         int lh, PolyConsts pc, hipStream_t st);
-void ffl_launch_flow_upsample(PairTab pt, int nB, int pw, int ph, int lw, int lh, hipStream_t st);
 // pw > 0: also produce the level's initial flow = x2 bilinear upsample of pt.prev (pw x ph) into pt.flow
 void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
                                 size_t M_stride, int lw, int lh, int pw, int ph, hipStream_t st);
@@ -78,7 +77,9 @@ void ffl_launch_radial(RadialTab rt, int nB, int w, int h, int pov_mode, double 
 // right next to it in time and its upper/lower neighbour FFL_PANEL_W tiles later, all on the same L2,
 // so stencil halos and gather neighbourhoods are re-read from L2 instead of over the fabric.
 // Grid: ffl_tile_grid(tiles_x, tiles_y, nB) workgroups, 1-D.  Returns false for padding workgroups.
+#ifndef FFL_PANEL_W
 #define FFL_PANEL_W 4
+#endif
 static inline unsigned ffl_tile_grid(int tiles_x, int tiles_y, int nB) {
     const int T = tiles_x * tiles_y;
     return (unsigned)(((T + 7) / 8) * 8 * nB);

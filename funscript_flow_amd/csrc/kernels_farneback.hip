@@ -52,8 +52,8 @@ __device__ __forceinline__ int ffl_reflect101(int p, int n) {
     return p;
 }
 
-__device__ __forceinline__ void ffl_resize_coord(int d, int src, int dst, int &i0, int &i1, float &f) {
-    double scale = (double)src / dst;
+// `scale` = (double)src / dst, formed once on the host (IEEE division: the same double the oracle forms)
+__device__ __forceinline__ void ffl_resize_coord(int d, int src, double scale, int &i0, int &i1, float &f) {
     float fx = (float)((d + 0.5) * scale - 0.5);
     int sx = (int)floorf(fx);
     fx -= sx;
@@ -75,6 +75,7 @@ struct PyrTile {
     int OW, OH;   // output tile (OW a power of two)
     int SW, SH;   // staged source window (max over tiles), SW odd
     int lgOW;
+    double sx, sy;  // (double)w / lw, (double)h / lh
 };
 
 // R > 0: blur radius known at compile time (taps unrolled, coefficients read once from the kernel
@@ -104,13 +105,13 @@ __global__ __launch_bounds__(256) void k_pyr_level(const uint8_t *__restrict__ g
     if (tid < nx) {
         int a, b;
         float f;
-        ffl_resize_coord(dx0 + tid, w, lw, a, b, f);
+        ffl_resize_coord(dx0 + tid, w, pt.sx, a, b, f);
         sX0[tid] = a; sX1[tid] = b; sFX[tid] = f;
     }
     if (tid >= 64 && tid - 64 < ny) {
         int a, b;
         float f;
-        ffl_resize_coord(dy0 + tid - 64, h, lh, a, b, f);
+        ffl_resize_coord(dy0 + tid - 64, h, pt.sy, a, b, f);
         sY0[tid - 64] = a; sY1[tid - 64] = b; sFY[tid - 64] = f;
     }
     __syncthreads();
@@ -227,6 +228,8 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut,
         size_t bytes = sizeof(float) * ((size_t)pt.SH * pt.SW + 2 * (size_t)pt.OW * (pt.SH | 1)) +
                        sizeof(int) * 3 * (size_t)(pt.OW + pt.OH);
         if (bytes <= 60 * 1024 || (pt.OW <= 8 && pt.OH <= 4)) {
+            pt.sx = (double)w / lw;
+            pt.sy = (double)h / lh;
             pt.lgOW = 0;
             while ((1 << pt.lgOW) < pt.OW) pt.lgOW++;
             dim3 grid((lw + pt.OW - 1) / pt.OW, (lh + pt.OH - 1) / pt.OH, nU);
@@ -326,49 +329,16 @@ void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stri
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: flow = resize(prevFlow, (lw, lh), INTER_LINEAR) * (1 / pyrScale)
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_flow_upsample(PairTab pt, int pw, int ph, int lw, int lh) {
-    int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    int b = blockIdx.z;
-    if (x >= lw || y >= lh) return;
-    const float2 *prev = reinterpret_cast<const float2 *>(pt.prev[b]);
-    float2 *flow = reinterpret_cast<float2 *>(pt.flow[b]);
-    int x0, x1, y0, y1;
-    float a1, b1;
-    ffl_resize_coord(x, pw, lw, x0, x1, a1);
-    ffl_resize_coord(y, ph, lh, y0, y1, b1);
-    float a0 = 1.f - a1, b0 = 1.f - b1;
-    float2 p00 = prev[(size_t)y0 * pw + x0], p01 = prev[(size_t)y0 * pw + x1];
-    float2 p10 = prev[(size_t)y1 * pw + x0], p11 = prev[(size_t)y1 * pw + x1];
-    float2 o;
-    {
-        float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
-        o.x = (t0 * b0 + t1 * b1) * 2.0f;
-    }
-    {
-        float t0 = p00.y * a0 + p01.y * a1, t1 = p10.y * a0 + p11.y * a1;
-        o.y = (t0 * b0 + t1 * b1) * 2.0f;
-    }
-    flow[(size_t)y * lw + x] = o;
-}
-
-void ffl_launch_flow_upsample(PairTab pt, int nB, int pw, int ph, int lw, int lh, hipStream_t st) {
-    dim3 grid((lw + 63) / 64, (lh + 3) / 4, nB);
-    hipLaunchKernelGGL(k_flow_upsample, grid, dim3(256), 0, st, pt, pw, ph, lw, lh);
-}
-
-// ------------------------------------------------------------------------------------------------
-// K4: FarnebackUpdateMatrices (standalone; runs once per level before the first blur iteration).
-// With UPSAMPLE the level's initial flow (K3: x2 bilinear upsample of the coarser level's result) is
-// produced here as well, written once and used from registers.  64x16 tiles in XCD-aware panel
-// order: the R1 rows y1, y1+1 gathered by vertically adjacent tiles are re-read from L2.
+// K3 + K4: FarnebackUpdateMatrices (standalone; runs once per level before the first blur
+// iteration).  With UPSAMPLE the level's initial flow -- K3: resize(prevFlow, (w, h), INTER_LINEAR)
+// * (1 / pyrScale) -- is produced here as well, written once and used from registers.  64x16 tiles
+// in XCD-aware panel order: the R1 rows y1, y1+1 gathered by vertically adjacent tiles are re-read
+// from L2.  usx / usy = (double)pw / w, (double)ph / h.
 // ------------------------------------------------------------------------------------------------
 template <bool UPSAMPLE>
 __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R, size_t R_stride, size_t plane,
                                                          PairTab pt, float *__restrict__ M, size_t M_stride, int w,
-                                                         int h, int pw, int ph) {
+                                                         int h, int pw, int ph, double usx, double usy) {
     int b, tile_x, tile_y;
     if (!ffl_tile_coord((w + 63) / 64, (h + 15) / 16, b, tile_x, tile_y)) return;
     const int x = tile_x * 64 + (threadIdx.x & 63);
@@ -378,37 +348,46 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
     const float2 *prev = reinterpret_cast<const float2 *>(pt.prev[b]);
     int x0 = 0, x1 = 0;
     float a1 = 0.f;
-    if (UPSAMPLE) ffl_resize_coord(x, pw, w, x0, x1, a1);
+    if (UPSAMPLE) ffl_resize_coord(x, pw, usx, x0, x1, a1);
+    // 4 rows per lane, branch-free (rows past the image are clamped for the loads and only their
+    // stores are predicated) so that the loads of all 4 rows are in flight together.
+    float2 f[4];
+    int ys[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        const int y = tile_y * 16 + (threadIdx.x >> 6) + 4 * k;
-        if (y >= h) break;
+        ys[k] = tile_y * 16 + (threadIdx.x >> 6) + 4 * k;
+        const int y = min(ys[k], h - 1);
         const size_t o = (size_t)y * w + x;
-        float2 f;
         if (UPSAMPLE) {
             int y0, y1;
             float b1;
-            ffl_resize_coord(y, ph, h, y0, y1, b1);
+            ffl_resize_coord(y, ph, usy, y0, y1, b1);
             const float a0 = 1.f - a1, b0 = 1.f - b1;
             const float2 p00 = prev[(size_t)y0 * pw + x0], p01 = prev[(size_t)y0 * pw + x1];
             const float2 p10 = prev[(size_t)y1 * pw + x0], p11 = prev[(size_t)y1 * pw + x1];
             {
                 float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
-                f.x = (t0 * b0 + t1 * b1) * 2.0f;
+                f[k].x = (t0 * b0 + t1 * b1) * 2.0f;
             }
             {
                 float t0 = p00.y * a0 + p01.y * a1, t1 = p10.y * a0 + p11.y * a1;
-                f.y = (t0 * b0 + t1 * b1) * 2.0f;
+                f[k].y = (t0 * b0 + t1 * b1) * 2.0f;
             }
-            flow[o] = f;
+            if (ys[k] < h) flow[o] = f[k];
         } else {
-            f = flow[o];
+            f[k] = flow[o];
         }
-        float m[5];
-        ffl_um_pixel(R0, R1, plane, w, h, x, y, f.x, f.y, m);
-        float *Mo = M + (size_t)b * M_stride + o;
+    }
 #pragma unroll
-        for (int c = 0; c < 5; c++) Mo[c * plane] = m[c];
+    for (int k = 0; k < 4; k++) {
+        const int y = min(ys[k], h - 1);
+        float m[5];
+        ffl_um_pixel(R0, R1, plane, w, h, x, y, f[k].x, f[k].y, m);
+        if (ys[k] < h) {
+            float *Mo = M + (size_t)b * M_stride + (size_t)y * w + x;
+#pragma unroll
+            for (int c = 0; c < 5; c++) Mo[c * plane] = m[c];
+        }
     }
 }
 
@@ -417,10 +396,10 @@ void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, P
     dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + 15) / 16, nB));
     if (pw > 0)
         hipLaunchKernelGGL(k_update_matrices<true>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
-                           pw, ph);
+                           pw, ph, (double)pw / lw, (double)ph / lh);
     else
         hipLaunchKernelGGL(k_update_matrices<false>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
-                           0, 0);
+                           0, 0, 1.0, 1.0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -546,19 +525,23 @@ __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *_
     const float2 *sF = reinterpret_cast<const float2 *>(sF4);
     const int lx = tid & 63, x = x0 + lx;
     if (x >= w) return;
+    // branch-free over the lane's TH/4 rows (clamped loads, predicated stores): all gathers in flight
 #pragma unroll
     for (int k = 0; k < TH / 4; k++) {
-        const int ly = (tid >> 6) + 4 * k, y = y0 + ly;
-        if (y >= h) break;
+        const int ly = (tid >> 6) + 4 * k;
+        const bool in = y0 + ly < h;
+        const int y = min(y0 + ly, h - 1);
         const float2 f = sF[ly * TW + lx];
         const size_t o = (size_t)y * w + x;
-        flow[o] = f;
+        if (in) flow[o] = f;
         if (UPDATE) {
             float m[5];
             ffl_um_pixel(R0, R1, plane, w, h, x, y, f.x, f.y, m);
-            float *Mo = Mout + (size_t)b * M_stride + o;
+            if (in) {
+                float *Mo = Mout + (size_t)b * M_stride + o;
 #pragma unroll
-            for (int c = 0; c < 5; c++) Mo[c * plane] = m[c];
+                for (int c = 0; c < 5; c++) Mo[c * plane] = m[c];
+            }
         }
     }
 }

@@ -125,6 +125,26 @@ class PairEngine:
         return dots, recs_all
 
 
+def frames_to_actions(engine, frames, fps, params):
+    """Gray (or BGR) frames of one video -> .funscript actions: the `process_video` body from frame
+    sampling to keyframes (FF:1127-1385) with the HIP pair engine in the middle.  `frames` holds every
+    decoded frame (any sequence); chunking follows FF:1145-1153 (pairs never span chunks, F10)."""
+    from . import postchain
+    step, _, indices = postchain.sampling(fps, len(frames))
+    bracket = int(params.get("batch_size", 3000.0))
+    dots, cuts, frame_idx = [], [], []
+    for cs in range(0, len(indices), bracket):
+        chunk = indices[cs:cs + bracket]
+        if len(chunk) < 2:
+            continue
+        d, recs = engine.process_chunk([frames[i] for i in chunk], bool(params.get("pov_mode", False)),
+                                       float(params.get("cut_threshold", 7)))
+        dots += [float(v) for v in d]
+        cuts += [bool(r[4]) for r in recs]
+        frame_idx += chunk[:-1]
+    return postchain.actions_from_scalars(dots, cuts, frame_idx, fps, params)
+
+
 def process_chunk_sharded(engine, frames, rank, world, allgather, pov_mode=False, cut_threshold=7.0):
     """Multi-GPU form of one chunk: rank r owns the contiguous pair block shard_range(n, world, r).
 

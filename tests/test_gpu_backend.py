@@ -90,6 +90,20 @@ def test_chunk_pipeline_matches_reference_chain(golden_dir):
     assert np.all(np.abs(np.array(dots) - d["dots"]) <= 1e-4 * np.maximum(np.abs(d["dots"]), scale))
 
 
+def test_end_to_end_funscript_matches_reference(golden_dir):
+    """BASELINE configs[0] shape, end to end on the HIP path: frames -> actions equals the .funscript
+    the real process_video wrote (with the oracle as its cv2.calcOpticalFlowFarneback)."""
+    meta = json.load(open(os.path.join(golden_dir, "chain_golden.json")))
+    s = meta["synth"]
+    frames = sine_translate_frames(meta["n_frames"], meta["size"], meta["size"], seed=s["seed"], amp=tuple(s["amp"]),
+                                   period=s["period"], zoom=s["zoom"])
+    if zlib.crc32(frames.tobytes()) != meta["frames_crc32"]:
+        pytest.skip("synthetic frames differ from the ones the golden was captured on (libm/numpy difference)")
+    with _capi.Context(meta["size"], meta["size"], max_batch=8, frame_slots=18, flow_slots=3 * 8 + 13) as ctx:
+        actions = pipeline.frames_to_actions(pipeline.PairEngine(ctx), frames, meta["fps"], meta["settings"])
+    assert actions == meta["funscript"]["actions"]
+
+
 def test_sharded_engine_single_rank_equals_chunk_engine():
     w, h = 160, 120
     frames = sine_translate_frames(14, w, h, seed=9, amp=(2.5, 1.0), period=7)

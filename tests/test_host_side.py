@@ -66,6 +66,32 @@ def test_smooth_centers_matches_reference_chain(golden_dir):
     assert pipeline.smooth_centers(np.zeros((0, 2))).shape == (0, 2)
 
 
+def test_postchain_reproduces_reference_funscript(golden_dir):
+    """integrate -> detrend -> smooth -> normalise -> keyframes -> actions, against
+    the .funscript the REAL process_video wrote (FF:1266-1394) for the same per-pair scalars."""
+    from funscript_flow_amd import postchain
+    d = np.load(os.path.join(golden_dir, "chain_golden.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "chain_golden.json")))
+    fps, n_frames, bs = meta["fps"], meta["n_frames"], meta["settings"]["batch_size"]
+    step, eff, indices = postchain.sampling(fps, n_frames)
+    assert (step, eff, len(indices)) == (1, 30.0, 41)
+    frame_idx = []
+    for cs in range(0, len(indices), bs):              # chunk[:-1] of every chunk with >= 2 frames (F10)
+        chunk = indices[cs:cs + bs]
+        if len(chunk) >= 2:
+            frame_idx += chunk[:-1]
+    assert len(frame_idx) == len(d["dots"])
+    actions = postchain.actions_from_scalars(list(d["dots"]), list(d["cut"]), frame_idx, fps, meta["settings"])
+    assert actions == meta["funscript"]["actions"]
+    # F7: with reduction off every sample becomes an action
+    raw = postchain.actions_from_scalars(list(d["dots"]), list(d["cut"]), frame_idx, fps,
+                                         dict(meta["settings"], keyframe_reduction=False))
+    assert len(raw) == len(frame_idx) and raw[0] == actions[0] and raw[-1] == actions[-1]
+    # cut handling: integration restarts at a cut and the jump is kept out of the detrend windows
+    cum = postchain.integrate([1.0, 1.0, 1.0, 5.0, 5.0], [False, False, False, True, False])
+    assert list(cum) == [0.0, 0.5, 1.5, 1.0, 2.5]
+
+
 def test_shard_range_partitions():
     for n in (0, 1, 7, 8, 39, 1000):
         for world in (1, 2, 3, 8):
