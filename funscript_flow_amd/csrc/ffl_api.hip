@@ -16,6 +16,8 @@
 #include <string>
 #include <vector>
 
+#define FFL_EV_RING 16
+
 static thread_local std::string g_create_error = "";
 static int g_num_lanes = 2;  // compute lanes per context created from now on (ffl_set_option "lanes")
 static bool g_run_ahead = false;  // frame-only kernels on a side stream (ffl_set_option "run_ahead"): +8 % with 1 lane, a loss with 2
@@ -47,7 +49,10 @@ struct ffl_ctx {
         // flow chain of the coarser levels, whose small grids leave most of the device idle; the
         // chain on `st` waits for ev_R[k] before touching level k.  R holds all levels at once.
         hipStream_t st_aux = nullptr;
-        hipEvent_t ev_R[8] = {nullptr}, ev_done = nullptr;
+        hipEvent_t ev_R[8] = {nullptr};
+        hipEvent_t ev_ring[FFL_EV_RING] = {nullptr};  // one "batch finished" event per batch, recycled
+        unsigned ring_next = 0;
+        hipEvent_t ev_done = nullptr;  // handle into ev_ring: the lane's latest batch
         size_t r_off[8] = {0};  // float offset of level k inside d_R
         float *d_I = nullptr, *d_R = nullptr, *d_M[2] = {nullptr, nullptr}, *d_flowA = nullptr, *d_flowB = nullptr;
         unsigned long long *d_pkey = nullptr;
@@ -60,16 +65,21 @@ struct ffl_ctx {
     uint8_t *d_bgr = nullptr;         // [n_fslots][3N] staging for 3-channel uploads
     uint8_t *h_stage = nullptr;       // pinned [n_fslots][3N]
     std::vector<hipEvent_t> ev_uploaded;
-    std::vector<hipEvent_t> ev_last_use;  // [frame slot * n_lanes + lane]
+    std::vector<hipEvent_t> ev_last_use;  // [frame slot * n_lanes + lane]: handle of the last batch event, or null
     std::vector<char> frame_valid;
+    hipEvent_t post_ring[FFL_EV_RING] = {nullptr};  // events of ffl_upload_flow (s_post)
+    unsigned post_next = 0;
     // flow slots
     float *d_flow = nullptr;          // [n_slots][2N]
-    Pass1Result *d_res = nullptr;     // [n_slots]
+    // Result records live in pinned, device-mapped host memory: the reduction kernels store their
+    // 24-byte record straight into it (visible after the slot's event), so no D2H copies are queued.
     Pass1Result *h_res = nullptr;     // pinned [n_slots]
+    Pass1Result *d_res = nullptr;     // device alias of h_res
     std::vector<hipEvent_t> ev_slot_done;
     std::vector<char> slot_state;     // 0 empty, 1 queued/ready
     std::vector<char> slot_pov;
-    double *d_rpsum = nullptr, *d_radial = nullptr, *h_radial = nullptr;  // pass-2 scratch (s_post)
+    double *d_rpsum = nullptr;                         // pass-2 partial sums (s_post)
+    double *h_radial = nullptr, *d_radial = nullptr;   // pinned pass-2 results and their device alias
     unsigned long long *d_ppkey = nullptr;                                 // ffl_upload_flow scratch (s_post)
     int p1_blocks = 0;
     // profiling
@@ -260,21 +270,22 @@ void ffl_destroy(ffl_ctx *c) {
     if (c->s_copy) hipStreamSynchronize(c->s_copy);
     prof_collect(c);
     for (auto e : c->ev_uploaded) hipEventDestroy(e);
-    for (auto e : c->ev_last_use) hipEventDestroy(e);
-    for (auto e : c->ev_slot_done) hipEventDestroy(e);
+    for (auto e : c->post_ring)
+        if (e) hipEventDestroy(e);
     hipFree(c->d_gray); hipFree(c->d_bgr); hipHostFree(c->h_stage);
     for (auto &L : c->lanes) {
         hipFree(L.d_I); hipFree(L.d_R); hipFree(L.d_M[0]); hipFree(L.d_M[1]);
         hipFree(L.d_flowA); hipFree(L.d_flowB); hipFree(L.d_pkey); hipFree(L.d_psum);
         for (auto e : L.ev_R)
             if (e) hipEventDestroy(e);
-        if (L.ev_done) hipEventDestroy(L.ev_done);
+        for (auto e : L.ev_ring)
+            if (e) hipEventDestroy(e);
         if (L.st_aux) hipStreamDestroy(L.st_aux);
         if (L.st) hipStreamDestroy(L.st);
     }
-    hipFree(c->d_flow); hipFree(c->d_res);
+    hipFree(c->d_flow);
     hipHostFree(c->h_res);
-    hipFree(c->d_rpsum); hipFree(c->d_ppkey); hipFree(c->d_radial); hipHostFree(c->h_radial);
+    hipFree(c->d_rpsum); hipFree(c->d_ppkey); hipHostFree(c->h_radial);
     if (c->s_copy) hipStreamDestroy(c->s_copy);
     if (c->s_post) hipStreamDestroy(c->s_post);
     delete c;
@@ -327,7 +338,7 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
         CCHK(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
         CCHK(hipMalloc(&L.d_I, sizeof(float) * N * maxU));
         CCHK(hipStreamCreateWithFlags(&L.st_aux, hipStreamNonBlocking));
-        CCHK(hipEventCreateWithFlags(&L.ev_done, hipEventDisableTiming));
+        for (auto &e : L.ev_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         size_t r_total = 0;
         for (int k = 0; k <= c->levels; k++) {
             CCHK(hipEventCreateWithFlags(&L.ev_R[k], hipEventDisableTiming));
@@ -343,21 +354,20 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
         CCHK(hipMalloc(&L.d_psum, sizeof(double) * c->p1_blocks * FFL_MAXB));
     }
     CCHK(hipMalloc(&c->d_flow, sizeof(float) * 2 * N * n_flow_slots));
-    CCHK(hipMalloc(&c->d_res, sizeof(Pass1Result) * n_flow_slots));
-    CCHK(hipHostMalloc(&c->h_res, sizeof(Pass1Result) * n_flow_slots, hipHostMallocDefault));
+    CCHK(hipHostMalloc(&c->h_res, sizeof(Pass1Result) * n_flow_slots, hipHostMallocMapped));
+    CCHK(hipHostGetDevicePointer((void **)&c->d_res, c->h_res, 0));
     CCHK(hipMalloc(&c->d_rpsum, sizeof(double) * c->p1_blocks * FFL_MAXB));
     CCHK(hipMalloc(&c->d_ppkey, sizeof(unsigned long long) * c->p1_blocks));
-    CCHK(hipMalloc(&c->d_radial, sizeof(double) * FFL_MAXB));
-    CCHK(hipHostMalloc(&c->h_radial, sizeof(double) * FFL_MAXB, hipHostMallocDefault));
+    CCHK(hipHostMalloc(&c->h_radial, sizeof(double) * FFL_MAXB, hipHostMallocMapped));
+    CCHK(hipHostGetDevicePointer((void **)&c->d_radial, c->h_radial, 0));
     c->ev_uploaded.resize(n_frame_slots);
-    c->ev_last_use.resize((size_t)n_frame_slots * g_num_lanes);
+    c->ev_last_use.assign((size_t)n_frame_slots * g_num_lanes, nullptr);  // handles into the lanes' rings
     c->frame_valid.assign(n_frame_slots, 0);
     for (int i = 0; i < n_frame_slots; i++) CCHK(hipEventCreateWithFlags(&c->ev_uploaded[i], hipEventDisableTiming));
-    for (auto &e : c->ev_last_use) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    c->ev_slot_done.resize(n_flow_slots);
+    for (auto &e : c->post_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    c->ev_slot_done.assign(n_flow_slots, nullptr);                        // handles, set when a slot is queued
     c->slot_state.assign(n_flow_slots, 0);
     c->slot_pov.assign(n_flow_slots, 0);
-    for (int i = 0; i < n_flow_slots; i++) CCHK(hipEventCreateWithFlags(&c->ev_slot_done[i], hipEventDisableTiming));
 #undef CCHK
     *out = c;
     return FFL_OK;
@@ -392,8 +402,10 @@ int ffl_upload_frame(ffl_ctx *c, int fslot, const uint8_t *data, int width, int 
     else
         for (int y = 0; y < height; y++) memcpy(stage + (size_t)y * row, data + (ptrdiff_t)y * stride_bytes, row);
     // the device copy of this slot may still be read by batches queued on any lane
-    for (size_t l = 0; l < c->lanes.size(); l++)
-        HIPCHK(c, hipStreamWaitEvent(c->s_copy, c->ev_last_use[(size_t)fslot * c->lanes.size() + l], 0));
+    for (size_t l = 0; l < c->lanes.size(); l++) {
+        hipEvent_t e = c->ev_last_use[(size_t)fslot * c->lanes.size() + l];
+        if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
+    }
     uint8_t *gray = c->d_gray + (size_t)fslot * N;
     if (channels == 1) {
         HIPCHK(c, hipMemcpyAsync(gray, stage, N, hipMemcpyHostToDevice, c->s_copy));
@@ -456,7 +468,7 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     const bool run_ahead = cap == nullptr && g_run_ahead;
     if (run_ahead) {
         hipStream_t sa = L.st_aux;
-        HIPCHK(c, hipStreamWaitEvent(sa, L.ev_done, 0));  // the lane's previous batch has finished with R
+        if (L.ev_done) HIPCHK(c, hipStreamWaitEvent(sa, L.ev_done, 0));  // the lane's previous batch is done with R
         for (int i = 0; i < nU; i++) HIPCHK(c, hipStreamWaitEvent(sa, c->ev_uploaded[ut.fslot[i]], 0));
         for (int k = c->levels; k >= 0; k--) {
             expand_level(k, sa);
@@ -476,8 +488,11 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
             pt.flow[i] = (k == 0) ? c->d_flow + (size_t)slots[i] * 2 * N : cur + (size_t)i * 2 * plane;
             pt.prev[i] = prv + (size_t)i * 2 * (size_t)pw * ph;
         }
-        if (pw == 0)
-            for (int i = 0; i < n; i++) HIPCHK(c, hipMemsetAsync(pt.flow[i], 0, sizeof(float) * 2 * plane, st));
+        if (pw == 0) {  // coarsest level starts from zero flow: one memset when the fields are contiguous
+            if (k > 0) HIPCHK(c, hipMemsetAsync(cur, 0, sizeof(float) * 2 * plane * n, st));
+            else
+                for (int i = 0; i < n; i++) HIPCHK(c, hipMemsetAsync(pt.flow[i], 0, sizeof(float) * 2 * plane, st));
+        }
         if (run_ahead) HIPCHK(c, hipStreamWaitEvent(st, L.ev_R[k], 0));
         else expand_level(k, st);
         int mi = 0;
@@ -521,11 +536,7 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         pw = lw;
         ph = lh;
     }
-    for (int i = 0; i < nU; i++)
-        HIPCHK(c, hipEventRecord(c->ev_last_use[(size_t)ut.fslot[i] * c->lanes.size() + li], st));
-    HIPCHK(c, hipEventRecord(L.ev_done, st));  // R / I of this lane may be overwritten from here on
-
-    // pass 1 on the finished level-0 flows
+    // pass 1 on the finished level-0 flows; records are stored straight into mapped pinned memory
     ResTab rtab;
     memset(&rtab, 0, sizeof(rtab));
     for (int i = 0; i < n; i++) rtab.r[i] = c->d_res + slots[i];
@@ -533,11 +544,14 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         ProfScope ps(c, FFL_K_PASS1, st);
         ffl_launch_pass1(pt, n, c->w, c->h, pov_mode, L.d_pkey, L.d_psum, rtab, st);
     }
+    // ONE event per batch: it marks the slots' results as ready, the frames' last use and the lane's
+    // work buffers as free (a ring, so handles held by older slots only ever point to later work)
+    hipEvent_t ev = L.ev_ring[L.ring_next++ % FFL_EV_RING];
+    HIPCHK(c, hipEventRecord(ev, st));
+    L.ev_done = ev;
+    for (int i = 0; i < nU; i++) c->ev_last_use[(size_t)ut.fslot[i] * c->lanes.size() + li] = ev;
     for (int i = 0; i < n; i++) {
-        HIPCHK(c, hipMemcpyAsync(c->h_res + slots[i], c->d_res + slots[i], sizeof(Pass1Result), hipMemcpyDeviceToHost, st));
-    }
-    for (int i = 0; i < n; i++) {
-        HIPCHK(c, hipEventRecord(c->ev_slot_done[slots[i]], st));
+        c->ev_slot_done[slots[i]] = ev;
         c->slot_state[slots[i]] = 1;
         c->slot_pov[slots[i]] = (char)(pov_mode != 0);
     }
@@ -629,8 +643,7 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
         ProfScope ps(c, FFL_K_RADIAL, st);
         ffl_launch_radial(rt, m, c->w, c->h, pov_mode, c->d_rpsum, c->d_radial, st);
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_radial, c->d_radial, sizeof(double) * m, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
+    HIPCHK(c, hipStreamSynchronize(st));  // k_radial_final stored into the mapped pinned buffer
     HIPCHK(c, hipGetLastError());
     for (int j = 0; j < m; j++) out[map[j]] = c->h_radial[j];
     return FFL_OK;
@@ -664,7 +677,7 @@ int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
         ProfScope ps(c, FFL_K_PASS1, st);
         ffl_launch_pass1(pt, 1, c->w, c->h, pov_mode, c->d_ppkey, c->d_rpsum, rtab, st);
     }
-    HIPCHK(c, hipMemcpyAsync(c->h_res + slot, c->d_res + slot, sizeof(Pass1Result), hipMemcpyDeviceToHost, st));
+    c->ev_slot_done[slot] = c->post_ring[c->post_next++ % FFL_EV_RING];
     HIPCHK(c, hipEventRecord(c->ev_slot_done[slot], st));
     c->slot_state[slot] = 1;
     c->slot_pov[slot] = (char)(pov_mode != 0);
