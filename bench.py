@@ -78,9 +78,11 @@ def main():
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
     ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows: 8 or 16")
     ap.add_argument("--lanes", type=int, default=0, help="compute lanes (co-scheduled batches) per context, default 1")
-    ap.add_argument("--run-ahead", action="store_true",
-                    help="pyramid + PolyExp of all levels on the lane's side stream, overlapping the coarse-level "
-                         "flow chain (+8 %% pairs/s with 1 lane; co-scheduled launches are stretched)")
+    ap.add_argument("--expand", type=int, default=0, choices=[0, 1, 2],
+                    help="schedule of the frame-only kernels (pyramid + PolyExp): 0 (default) serial on the lane's "
+                         "stream; 2 the 4 levels fork onto side streams and join before the flow chain starts; "
+                         "1 run-ahead, the chain waits per level (coarse-level flow launches get co-scheduled and "
+                         "stretched: +3 %% pairs/s)")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the process group is gloo")
     ap.add_argument("--no-events", action="store_true", help="diagnostic: no per-kernel HIP events (roofline omitted)")
@@ -124,7 +126,7 @@ def main():
     # rocprofv3's).  `--lanes 2` (the library's default for production use) co-schedules two batches:
     # ~+11 % pairs/s at 1080p, but every launch is stretched by its co-runner (profiles/README.md).
     _capi.set_option("lanes", args.lanes or 1)
-    _capi.set_option("run_ahead", 1 if args.run_ahead else 0)
+    _capi.set_option("run_ahead", args.expand)
     W, H, B = args.width, args.height, args.batch
     N = W * H
     U = 2 * B if args.independent else B + 1

@@ -20,7 +20,9 @@
 
 static thread_local std::string g_create_error = "";
 static int g_num_lanes = 2;  // compute lanes per context created from now on (ffl_set_option "lanes")
-static bool g_run_ahead = false;  // frame-only kernels on a side stream (ffl_set_option "run_ahead"): +8 % with 1 lane, a loss with 2
+// Schedule of the frame-only kernels (ffl_set_option "run_ahead", see run_batch).  Measured at 1080p, B = 8
+// (pairs/s with 1 / 2 lanes): 0 serial 3840 / 4063, 2 fork-join 3641 / 4101, 1 run-ahead 3943 / 4159.
+static int g_run_ahead = 0;
 
 struct ProfRec {
     int cls;
@@ -48,8 +50,9 @@ struct ffl_ctx {
         // Frame-only work (pyramid + PolyExp of every level) runs ahead on `st_aux` and overlaps the
         // flow chain of the coarser levels, whose small grids leave most of the device idle; the
         // chain on `st` waits for ev_R[k] before touching level k.  R holds all levels at once.
-        hipStream_t st_aux = nullptr;
-        hipEvent_t ev_R[8] = {nullptr};
+        hipStream_t st_aux[4] = {nullptr};
+        hipEvent_t ev_R[8] = {nullptr}, ev_fork = nullptr;
+        size_t i_off[8] = {0};  // float offset of level k inside d_I
         hipEvent_t ev_ring[FFL_EV_RING] = {nullptr};  // one "batch finished" event per batch, recycled
         unsigned ring_next = 0;
         hipEvent_t ev_done = nullptr;  // handle into ev_ring: the lane's latest batch
@@ -280,7 +283,9 @@ void ffl_destroy(ffl_ctx *c) {
             if (e) hipEventDestroy(e);
         for (auto e : L.ev_ring)
             if (e) hipEventDestroy(e);
-        if (L.st_aux) hipStreamDestroy(L.st_aux);
+        if (L.ev_fork) hipEventDestroy(L.ev_fork);
+        for (auto s : L.st_aux)
+            if (s) hipStreamDestroy(s);
         if (L.st) hipStreamDestroy(L.st);
     }
     hipFree(c->d_flow);
@@ -336,15 +341,18 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     c->lanes.resize(g_num_lanes);
     for (auto &L : c->lanes) {
         CCHK(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
-        CCHK(hipMalloc(&L.d_I, sizeof(float) * N * maxU));
-        CCHK(hipStreamCreateWithFlags(&L.st_aux, hipStreamNonBlocking));
+        for (auto &s : L.st_aux) CCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        CCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
         for (auto &e : L.ev_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        size_t r_total = 0;
+        size_t r_total = 0, i_total = 0;
         for (int k = 0; k <= c->levels; k++) {
             CCHK(hipEventCreateWithFlags(&L.ev_R[k], hipEventDisableTiming));
             L.r_off[k] = r_total;
+            L.i_off[k] = i_total;
             r_total += (size_t)5 * c->geom[k].lw * c->geom[k].lh * maxU;
+            i_total += (size_t)c->geom[k].lw * c->geom[k].lh * maxU;
         }
+        CCHK(hipMalloc(&L.d_I, sizeof(float) * i_total));
         CCHK(hipMalloc(&L.d_R, sizeof(float) * r_total));
         CCHK(hipMalloc(&L.d_M[0], sizeof(float) * 5 * N * max_batch));
         CCHK(hipMalloc(&L.d_M[1], sizeof(float) * 5 * N * max_batch));
@@ -458,23 +466,34 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         const size_t plane = (size_t)g.lw * g.lh;
         {
             ProfScope ps(c, FFL_K_PYRAMID, s);
-            ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, g.lw, g.lh, g.gk, L.d_I, plane, s);
+            ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, g.lw, g.lh, g.gk, L.d_I + L.i_off[k], plane, s);
         }
         {
             ProfScope ps(c, FFL_K_POLYEXP, s);
-            ffl_launch_polyexp(L.d_I, plane, L.d_R + L.r_off[k], 5 * plane, plane, nU, g.lw, g.lh, c->pc, s);
+            ffl_launch_polyexp(L.d_I + L.i_off[k], plane, L.d_R + L.r_off[k], 5 * plane, plane, nU, g.lw, g.lh, c->pc, s);
         }
     };
-    const bool run_ahead = cap == nullptr && g_run_ahead;
-    if (run_ahead) {
-        hipStream_t sa = L.st_aux;
-        if (L.ev_done) HIPCHK(c, hipStreamWaitEvent(sa, L.ev_done, 0));  // the lane's previous batch is done with R
-        for (int i = 0; i < nU; i++) HIPCHK(c, hipStreamWaitEvent(sa, c->ev_uploaded[ut.fslot[i]], 0));
+    // Frame-only expansion schedule (ffl_set_option "run_ahead"):
+    //   0  serial, on the lane's stream, level by level (also used for debug capture)
+    //   2  fork/join: the 4 levels expand concurrently on side streams (their small grids and serial
+    //      LDS phases leave most of the device idle when run one after the other), and the flow chain
+    //      starts only after all of them -- it is never co-scheduled with anything
+    //   1  run-ahead: one side stream, the chain waits per level, so coarse-level flow kernels overlap
+    //      the finer levels' expansion (fastest with one lane, but stretches those launches)
+    const int mode = cap ? 0 : g_run_ahead;
+    if (mode) {
+        HIPCHK(c, hipEventRecord(L.ev_fork, st));  // after the uploads and after the lane's previous batch
         for (int k = c->levels; k >= 0; k--) {
+            hipStream_t sa = L.st_aux[mode == 2 ? k : 0];
+            if (mode == 2 || k == c->levels) HIPCHK(c, hipStreamWaitEvent(sa, L.ev_fork, 0));
             expand_level(k, sa);
             HIPCHK(c, hipEventRecord(L.ev_R[k], sa));
         }
+        if (mode == 2)
+            for (int k = c->levels; k >= 0; k--) HIPCHK(c, hipStreamWaitEvent(st, L.ev_R[k], 0));
     }
+    const bool run_ahead = mode == 1;
+    const bool expanded = mode != 0;
 
     float *cur = L.d_flowA, *prv = L.d_flowB;
     int pw = 0, ph = 0;
@@ -494,7 +513,7 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
                 for (int i = 0; i < n; i++) HIPCHK(c, hipMemsetAsync(pt.flow[i], 0, sizeof(float) * 2 * plane, st));
         }
         if (run_ahead) HIPCHK(c, hipStreamWaitEvent(st, L.ev_R[k], 0));
-        else expand_level(k, st);
+        else if (!expanded) expand_level(k, st);
         int mi = 0;
         {
             ProfScope ps(c, FFL_K_UPDATE_MATRICES, st);
@@ -504,8 +523,8 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         bool captured = false;
         auto capture = [&]() -> int {
             HIPCHK(c, hipStreamSynchronize(st));
-            if (cap->I0) HIPCHK(c, hipMemcpy(cap->I0, L.d_I + (size_t)pt.u0[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
-            if (cap->I1) HIPCHK(c, hipMemcpy(cap->I1, L.d_I + (size_t)pt.u1[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
+            if (cap->I0) HIPCHK(c, hipMemcpy(cap->I0, L.d_I + L.i_off[k] + (size_t)pt.u0[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
+            if (cap->I1) HIPCHK(c, hipMemcpy(cap->I1, L.d_I + L.i_off[k] + (size_t)pt.u1[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
             if (cap->R0) HIPCHK(c, hipMemcpy(cap->R0, Rk + (size_t)pt.u0[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
             if (cap->R1) HIPCHK(c, hipMemcpy(cap->R1, Rk + (size_t)pt.u1[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
             if (cap->M) HIPCHK(c, hipMemcpy(cap->M, L.d_M[mi], sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
@@ -719,8 +738,9 @@ int ffl_set_option(const char *name, int value) {
         g_num_lanes = value;
         return FFL_OK;
     }
-    if (!strcmp(name, "run_ahead")) {  // 1: pyramid + PolyExp of all levels on the lane's side stream
-        g_run_ahead = value != 0;
+    if (!strcmp(name, "run_ahead")) {  // frame-only expansion schedule: 0 serial, 1 run-ahead, 2 fork/join
+        if (value < 0 || value > 2) return FFL_ERR_INVALID;
+        g_run_ahead = value;
         return FFL_OK;
     }
     return FFL_ERR_INVALID;
