@@ -10,7 +10,8 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libffl_hip.so")
 
 FFL_OK = 0
 FFL_MAX_BATCH = 32
-KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "k_flow_upsample", "k_update_matrices", "k_blur_solve",
+# kernel classes of ffl_profile_read (index 3 is reserved: the x2 flow upsample is fused into k_update_matrices)
+KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "(reserved)", "k_update_matrices", "k_blur_solve",
                   "k_pass1", "k_radial"]
 
 # every symbol include/ffl.h declares (tests check that the library exports all of them)

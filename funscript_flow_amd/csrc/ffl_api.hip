@@ -1,10 +1,13 @@
 // C ABI (include/ffl.h) of the gfx950 pair-motion path: context, slots, streams, batch schedule.
 //
-// Streams: `copy` carries the pinned H2D frame transfers (+ the BGR->gray kernel); `compute`
-// carries everything else.  compute waits on a frame's upload event; an upload into a frame slot
-// waits on the event of the last batch that read it.  No host synchronisation happens inside
-// ffl_upload_frame / ffl_flow_pairs, so uploads of the next frames overlap the kernels of the
-// previous batch (north_star: "staged to HBM via pinned hipMemcpyAsync on a side stream").
+// Streams: `copy` carries the pinned H2D frame transfers (+ the BGR->gray kernel); every compute lane
+// has its own stream (+ side streams for the optional run-ahead schedules) and work buffers; `post`
+// carries pass 2.  A batch waits on its frames' upload events; an upload into a frame slot waits on
+// the batch events of the lanes that last read it; each batch records ONE event that stands for "slots
+// ready / frames released / lane buffers free".  Result records are stored by the reduction kernels
+// straight into mapped pinned memory, so no tiny D2H copies are queued.  No host synchronisation
+// happens inside ffl_upload_frame / ffl_flow_pairs, so uploads of the next frames overlap the kernels
+// of the previous batch (north_star: "staged to HBM via pinned hipMemcpyAsync on a side stream").
 #include "../../include/ffl.h"
 #include "ffl_kernels.h"
 
@@ -53,6 +56,8 @@ struct ffl_ctx {
         hipStream_t st_aux[4] = {nullptr};
         hipEvent_t ev_R[8] = {nullptr}, ev_fork = nullptr;
         size_t i_off[8] = {0};  // float offset of level k inside d_I
+        size_t t_off[8] = {0};  // float offset of level k inside d_T (pyramid horizontal-pass buffer)
+        float *d_T = nullptr;
         hipEvent_t ev_ring[FFL_EV_RING] = {nullptr};  // one "batch finished" event per batch, recycled
         unsigned ring_next = 0;
         hipEvent_t ev_done = nullptr;  // handle into ev_ring: the lane's latest batch
@@ -259,7 +264,7 @@ int ffl_device_count(void) {
 const char *ffl_last_error(const ffl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 const char *ffl_kernel_name(int k) {
-    static const char *names[FFL_K_COUNT] = {"k_gray",  "k_pyr_level", "k_polyexp", "k_flow_upsample",
+    static const char *names[FFL_K_COUNT] = {"k_gray",  "k_pyr_level", "k_polyexp", "(reserved)",
                                              "k_update_matrices", "k_blur_solve", "k_pass1", "k_radial"};
     return (k >= 0 && k < FFL_K_COUNT) ? names[k] : "?";
 }
@@ -277,7 +282,7 @@ void ffl_destroy(ffl_ctx *c) {
         if (e) hipEventDestroy(e);
     hipFree(c->d_gray); hipFree(c->d_bgr); hipHostFree(c->h_stage);
     for (auto &L : c->lanes) {
-        hipFree(L.d_I); hipFree(L.d_R); hipFree(L.d_M[0]); hipFree(L.d_M[1]);
+        hipFree(L.d_I); hipFree(L.d_T); hipFree(L.d_R); hipFree(L.d_M[0]); hipFree(L.d_M[1]);
         hipFree(L.d_flowA); hipFree(L.d_flowB); hipFree(L.d_pkey); hipFree(L.d_psum);
         for (auto e : L.ev_R)
             if (e) hipEventDestroy(e);
@@ -334,7 +339,7 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     CCHK(hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking));
     const size_t N = c->N;
     const int maxU = 2 * max_batch;
-    CCHK(hipMalloc(&c->d_gray, (size_t)n_frame_slots * N));
+    CCHK(hipMalloc(&c->d_gray, (size_t)n_frame_slots * N + 16));  // +16: k_pyr_h fetches taps as aligned words
     CCHK(hipMalloc(&c->d_bgr, (size_t)n_frame_slots * N * 3));
     CCHK(hipHostMalloc(&c->h_stage, (size_t)n_frame_slots * N * 3, hipHostMallocDefault));
     c->p1_blocks = ffl_pass1_blocks(width, height);
@@ -344,15 +349,18 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
         for (auto &s : L.st_aux) CCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
         CCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
         for (auto &e : L.ev_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        size_t r_total = 0, i_total = 0;
+        size_t r_total = 0, i_total = 0, t_total = 0;
         for (int k = 0; k <= c->levels; k++) {
             CCHK(hipEventCreateWithFlags(&L.ev_R[k], hipEventDisableTiming));
             L.r_off[k] = r_total;
             L.i_off[k] = i_total;
+            L.t_off[k] = t_total;
+            t_total += ffl_pyr_tmp_floats(width, height, c->geom[k].lw) * maxU;
             r_total += (size_t)5 * c->geom[k].lw * c->geom[k].lh * maxU;
             i_total += (size_t)c->geom[k].lw * c->geom[k].lh * maxU;
         }
         CCHK(hipMalloc(&L.d_I, sizeof(float) * i_total));
+        CCHK(hipMalloc(&L.d_T, sizeof(float) * t_total));
         CCHK(hipMalloc(&L.d_R, sizeof(float) * r_total));
         CCHK(hipMalloc(&L.d_M[0], sizeof(float) * 5 * N * max_batch));
         CCHK(hipMalloc(&L.d_M[1], sizeof(float) * 5 * N * max_batch));
@@ -466,7 +474,8 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         const size_t plane = (size_t)g.lw * g.lh;
         {
             ProfScope ps(c, FFL_K_PYRAMID, s);
-            ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, g.lw, g.lh, g.gk, L.d_I + L.i_off[k], plane, s);
+            ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, g.lw, g.lh, g.gk, L.d_T + L.t_off[k],
+                                 ffl_pyr_tmp_floats(c->w, c->h, g.lw), L.d_I + L.i_off[k], plane, s);
         }
         {
             ProfScope ps(c, FFL_K_POLYEXP, s);

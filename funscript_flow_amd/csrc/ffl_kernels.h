@@ -47,8 +47,9 @@ struct Pass1Result {  // written by k_pass1_final, mirrored to pinned host memor
 
 // ---- launchers (each enqueues on `st` and returns; no synchronisation) ----------------------
 void ffl_launch_gray(const uint8_t *bgr, uint8_t *gray, int n_pixels, hipStream_t st);
+size_t ffl_pyr_tmp_floats(int w, int h, int lw);  // per-frame size of the level's horizontal-pass buffer
 void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, int lw, int lh,
-                          GaussKernel gk, float *I, size_t I_stride, hipStream_t st);
+                          GaussKernel gk, float *tmp, size_t tmp_stride, float *I, size_t I_stride, hipStream_t st);
 void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stride, size_t plane, int nU, int lw,
                         int lh, PolyConsts pc, hipStream_t st);
 // pw > 0: also produce the level's initial flow = x2 bilinear upsample of pt.prev (pw x ph) into pt.flow
@@ -98,12 +99,19 @@ __device__ __forceinline__ bool ffl_tile_coord(int tiles_x, int tiles_y, int &b,
     return true;
 }
 
-// update-matrices body shared by the standalone kernel and the fused blur+solve+update kernel
-__device__ __forceinline__ void ffl_um_pixel(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,
-                                             int w, int h, int x, int y, float dx, float dy, float out[5]) {
+// 8- and 16-byte vectors that are only 4-byte aligned: gfx950 global loads/stores of dwordx2/x4 need
+// dword alignment only, and every vector-memory wave-instruction costs the texture-address unit the
+// same ~16 cycles whatever its width -- halving the instruction count is what speeds these kernels up.
+struct __attribute__((packed, aligned(4))) ffl_f2u { float x, y; };
+struct __attribute__((packed, aligned(4))) ffl_f4u { float x, y, z, w; };
+
+// update-matrices body shared by the standalone kernel and the fused blur+solve+update kernel.
+// r0[5] are the R0 coefficients of pixel (x, y); the R1 neighbourhood is gathered here, the two
+// horizontally adjacent bilinear corners with one 8-byte load each.
+__device__ __forceinline__ void ffl_um_core(const float (&r0)[5], const float *__restrict__ R1, size_t plane, int w,
+                                            int h, int x, int y, float dx, float dy, float (&out)[5]) {
     // border[5] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} as selects (no runtime-indexed array)
 #define FFL_BORDER(i) ((i) < 2 ? 0.14f : 0.4472f)
-    size_t o = (size_t)y * w + x;
     float fx = x + dx, fy = y + dy;
     int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     float r2, r3, r4, r5, r6;
@@ -112,24 +120,26 @@ __device__ __forceinline__ void ffl_um_pixel(const float *__restrict__ R0, const
     if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
         float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
         const float *p = R1 + (size_t)y1 * w + x1;
-#define FFL_BIL(c) (a00 * p[(c)*plane] + a01 * p[(c)*plane + 1] + a10 * p[(c)*plane + w] + a11 * p[(c)*plane + w + 1])
-        r2 = FFL_BIL(0);
-        r3 = FFL_BIL(1);
-        r4 = FFL_BIL(2);
-        r5 = FFL_BIL(3);
-        r6 = FFL_BIL(4);
-#undef FFL_BIL
-        r4 = (R0[2 * plane + o] + r4) * 0.5f;
-        r5 = (R0[3 * plane + o] + r5) * 0.5f;
-        r6 = (R0[4 * plane + o] + r6) * 0.25f;
+        float b[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const ffl_f2u t = *reinterpret_cast<const ffl_f2u *>(p + c * plane);      // (x1, y1), (x1+1, y1)
+            const ffl_f2u u = *reinterpret_cast<const ffl_f2u *>(p + c * plane + w);  // (x1, y1+1), (x1+1, y1+1)
+            b[c] = a00 * t.x + a01 * t.y + a10 * u.x + a11 * u.y;
+        }
+        r2 = b[0];
+        r3 = b[1];
+        r4 = (r0[2] + b[2]) * 0.5f;
+        r5 = (r0[3] + b[3]) * 0.5f;
+        r6 = (r0[4] + b[4]) * 0.25f;
     } else {
         r2 = r3 = 0.f;
-        r4 = R0[2 * plane + o];
-        r5 = R0[3 * plane + o];
-        r6 = R0[4 * plane + o] * 0.5f;
+        r4 = r0[2];
+        r5 = r0[3];
+        r6 = r0[4] * 0.5f;
     }
-    r2 = (R0[o] - r2) * 0.5f;
-    r3 = (R0[plane + o] - r3) * 0.5f;
+    r2 = (r0[0] - r2) * 0.5f;
+    r3 = (r0[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
     r3 += r6 * dy + r5 * dx;
     if ((unsigned)(x - 5) >= (unsigned)(w - 10) || (unsigned)(y - 5) >= (unsigned)(h - 10)) {
@@ -143,4 +153,39 @@ __device__ __forceinline__ void ffl_um_pixel(const float *__restrict__ R0, const
     out[2] = r5 * r5 + r6 * r6;
     out[3] = r4 * r2 + r6 * r3;
     out[4] = r6 * r2 + r5 * r3;
+}
+
+// Two horizontally adjacent pixels (x, y), (x+1, y) per lane: R0 read and M written with 8-byte
+// accesses.  `second` is false when x+1 is outside the image; `store` predicates the M writes.
+__device__ __forceinline__ void ffl_um_pair(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,
+                                            int w, int h, int x, int y, float2 f0, float2 f1, bool second, bool store,
+                                            float *__restrict__ Mo) {
+    const size_t o = (size_t)y * w + x;
+    float ra[5], rb[5], ma[5], mb[5];
+    if (second) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const ffl_f2u t = *reinterpret_cast<const ffl_f2u *>(R0 + c * plane + o);
+            ra[c] = t.x;
+            rb[c] = t.y;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 5; c++) ra[c] = rb[c] = R0[c * plane + o];
+    }
+    ffl_um_core(ra, R1, plane, w, h, x, y, f0.x, f0.y, ma);
+    ffl_um_core(rb, R1, plane, w, h, second ? x + 1 : x, y, f1.x, f1.y, mb);
+    if (!store) return;
+    if (second) {
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            ffl_f2u t;
+            t.x = ma[c];
+            t.y = mb[c];
+            *reinterpret_cast<ffl_f2u *>(Mo + c * plane + o) = t;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 5; c++) Mo[c * plane + o] = ma[c];
+    }
 }

@@ -6,8 +6,8 @@
 //   k_gray          HBM        4 per full-res pixel (3 in, 1 out)
 //   k_pyr_level     HBM/L1     1 per full-res pixel in + 4 per level pixel out
 //   k_polyexp       HBM        24  (4 in, 20 out), 11x11 separable through LDS
-//   k_flow_upsample HBM        10  (2 in at quarter res, 8 out)
-//   k_update_mat    HBM        68  (R0 20 + R1 gather 20 + flow 8 -> M 20)
+//   k_update_mat    HBM        68  (R0 20 + R1 gather 20 + flow 8 -> M 20); also forms the level's
+//                              initial flow (x2 upsample: 2 in at quarter res + 8 out) in the same pass
 //   k_blur_solve    HBM        28  (M 20 -> flow 8) [+68 when the next UpdateMatrices is fused]
 #include "ffl_kernels.h"
 
@@ -64,188 +64,236 @@ __device__ __forceinline__ void ffl_resize_coord(int d, int src, double scale, i
     f = fx;
 }
 
-// One OW x OH output tile per 256-thread workgroup, three LDS stages:
-//   stage   the full-resolution source window the tile samples (+ blur radius), uint8 -> float,
-//           REFLECT_101 resolved here so the filter loops below are branch-free;
-//   H pass  horizontal blur of every staged row at the (<= 2 per output) sampled columns; lanes run
-//           along rows and the row pitch is odd, so the strided column reads are conflict-free;
-//   V pass  vertical blur at the (<= 2) sampled rows + the two lerps, one output per lane.
+// Two plain streaming kernels per level, no LDS and no barriers (the earlier LDS-tiled version spent
+// its time in four dependent phases per workgroup and never filled the device at the coarse levels):
+//   k_pyr_h  one lane per (row y, output column d, lerp side q): horizontal blur of the full-resolution
+//            row at the sampled column -> tmp[y][d][q]            (float, symmetric form, REFLECT_101)
+//   k_pyr_v  one lane per output pixel: vertical blur of tmp at the (<= 2) sampled rows for the
+//            (<= 2) sampled columns, then the two lerps -> I
 // Samples whose lerp weight is exactly 0 are not evaluated: v*1 + s*0 == v for finite s >= 0.
-struct PyrTile {
-    int OW, OH;   // output tile (OW a power of two)
-    int SW, SH;   // staged source window (max over tiles), SW odd
-    int lgOW;
-    double sx, sy;  // (double)w / lw, (double)h / lh
-};
-
-// R > 0: blur radius known at compile time (taps unrolled, coefficients read once from the kernel
-// arguments into scalar registers); R == 0: runtime radius.
+// R > 0: blur radius known at compile time (taps unrolled, coefficients in scalar registers);
+// R == 0: runtime radius.  nq = 2 when the level resamples in x (lw != w), else 1.
+// rows per lane of k_pyr_h: enough loads in flight to cover the memory latency without spilling
+// (a row costs 2R+1 byte loads)
+constexpr int ffl_pyr_rows(int R) { return R == 1 ? 16 : (R == 4 ? 8 : 4); }
+constexpr int ffl_pyr_vrows(int R) { return R == 1 ? 4 : 1; }  // output rows per lane of k_pyr_v
 template <int R>
-__global__ __launch_bounds__(256) void k_pyr_level(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
-                                                   int w, int h, int lw, int lh, GaussKernel gk,
-                                                   float *__restrict__ I, size_t I_stride, PyrTile pt) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int OW = pt.OW, OH = pt.OH, SW = pt.SW, SH = pt.SH;
-    const int HP = SH | 1;                      // row pitch (in columns) of the H-pass planes: odd
-    float *sSrc = smem;                         // [SH][SW]
-    float *sH = sSrc + SH * SW;                 // [2][OW][HP]  (q, output column, staged row)
-    int *sX0 = reinterpret_cast<int *>(sH + 2 * OW * HP);  // per output column: x0, x1
-    int *sX1 = sX0 + OW;
-    float *sFX = reinterpret_cast<float *>(sX1 + OW);
-    int *sY0 = reinterpret_cast<int *>(sFX + OW);
-    int *sY1 = sY0 + OH;
-    float *sFY = reinterpret_cast<float *>(sY1 + OH);
-
-    const int tid = threadIdx.x, u = blockIdx.z;
-    const int dx0 = blockIdx.x * OW, dy0 = blockIdx.y * OH;
-    const int nx = min(OW, lw - dx0), ny = min(OH, lh - dy0);
+__global__ __launch_bounds__(256) void k_pyr_h(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut, int w,
+                                               int h, int lw, int nq, double sx, GaussKernel gk,
+                                               float *__restrict__ tmp, size_t tmp_stride) {
+    // each lane produces ROWS rows of its column (one workgroup per 256 outputs would be bound by the
+    // workgroup dispatch rate, not by memory)
+    constexpr int ROWS = ffl_pyr_rows(R);
+    const int i = blockIdx.x * 256 + threadIdx.x, u = blockIdx.z;
+    if (i >= lw * nq) return;
+    const int d = nq == 2 ? i >> 1 : i, q = nq == 2 ? (i & 1) : 0;
     const int r = R > 0 ? R : (gk.ksize >> 1);
+    int x0, x1;
+    float fx;
+    ffl_resize_coord(d, w, sx, x0, x1, fx);
+    const bool on = q == 0 || fx != 0.f;
+    const int cx = q ? x1 : x0;
+    const bool interior = cx >= r && cx + r < w;
+    int xm[R > 0 ? R : 1], xp[R > 0 ? R : 1];  // reflected tap columns (border lanes, compile-time radius)
+    if (R > 0) {
+#pragma unroll
+        for (int t = 1; t <= R; t++) {
+            xm[t - 1] = ffl_reflect101(cx - t, w);
+            xp[t - 1] = ffl_reflect101(cx + t, w);
+        }
+    }
     const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
-
-    if (tid < nx) {
-        int a, b;
-        float f;
-        ffl_resize_coord(dx0 + tid, w, pt.sx, a, b, f);
-        sX0[tid] = a; sX1[tid] = b; sFX[tid] = f;
-    }
-    if (tid >= 64 && tid - 64 < ny) {
-        int a, b;
-        float f;
-        ffl_resize_coord(dy0 + tid - 64, h, pt.sy, a, b, f);
-        sY0[tid - 64] = a; sY1[tid - 64] = b; sFY[tid - 64] = f;
-    }
-    __syncthreads();
-    const int xs = sX0[0] - r, ys = sY0[0] - r;
-    const int span_w = sX1[nx - 1] + r - xs + 1, span_h = sY1[ny - 1] + r - ys + 1;  // <= SW, SH by construction
-
-    const int lane = tid & 63, wv = tid >> 6;  // all loops below are (wave, lane) nests: no divisions
-    for (int j = wv; j < span_h; j += 4) {
-        const uint8_t *row = img + (size_t)ffl_reflect101(ys + j, h) * w;
-        for (int c = lane; c < span_w; c += 64) sSrc[j * SW + c] = (float)row[ffl_reflect101(xs + c, w)];
-    }
-    __syncthreads();
-
-    // H pass -> sH[q][d][j].  q = 1 (the right lerp neighbour) is needed only when resampling in x.
-    const int nq = (lw != w) ? 2 : 1;
-    if (pt.OW >= 32) {
-        // mild decimation: lanes along output columns (source stride <= 4 floats), waves along rows
-        for (int q = 0; q < nq; q++)
-            for (int d = lane; d < nx; d += 64) {
-                const bool on = q == 0 || sFX[d] != 0.f;
-                const float *p0 = sSrc + ((q ? sX1[d] : sX0[d]) - xs);
-                for (int j = wv; j < span_h; j += 4) {
-                    float acc = 0.f;
-                    if (on) {
-                        const float *p = p0 + j * SW;
-                        acc = gk.k[r] * p[0];
+    float *out = tmp + (size_t)u * tmp_stride + i;
+    const int ybase = blockIdx.y * ROWS;
+    // word-wise tap fetch needs 4-byte aligned rows (w % 4 == 0; frame slots are w*h apart) and all
+    // taps inside the row; the last word may reach <= 3 bytes past the taps, still inside the slot array
+    // (the gray buffer is allocated with 16 bytes of slack)
+    const int wfirst = cx - r, woff = wfirst & 3, wbase = wfirst - woff;
+    const bool wide = R > 0 && interior && (w & 3) == 0;
+    // fixed trip count, rows clamped for the loads and predicated for the store: the loop unrolls and
+    // the loads of all rows are in flight together (a rolled loop pays one memory latency per row)
 #pragma unroll
-                        for (int t = 1; t <= r; t++) acc = acc + gk.k[r + t] * (p[-t] + p[t]);
-                    }
-                    sH[(q * OW + d) * HP + j] = acc;
-                }
-            }
-    } else {
-        // strong decimation: lanes along staged rows (odd pitch: conflict-free), waves along (q, d)
-        for (int dq = wv; dq < nq * nx; dq += 4) {
-            const int q = dq >= nx, d = q ? dq - nx : dq;
-            const bool on = q == 0 || sFX[d] != 0.f;
-            const float *p0 = sSrc + ((q ? sX1[d] : sX0[d]) - xs);
-            for (int j = lane; j < span_h; j += 64) {
-                float acc = 0.f;
-                if (on) {
-                    const float *p = p0 + j * SW;
-                    acc = gk.k[r] * p[0];
+    for (int k = 0; k < ROWS; k++) {
+        const int y = min(ybase + k, h - 1);
+        float acc = 0.f;
+        if (on) {
+            const uint8_t *row = img + (size_t)y * w;
+            if (R > 0 && wide) {
+                // interior lane: the 2R+1 taps sit in NW aligned 32-bit words -> NW loads instead of
+                // 2R+1 byte loads (the texture-address unit is paid per wave-instruction, not per byte),
+                // re-aligned with v_alignbyte, bytes converted with v_cvt_f32_ubyteN
+                constexpr int NW = (3 + 2 * R + 1 + 3) / 4;
+                const uint32_t *wp = reinterpret_cast<const uint32_t *>(row + wbase);
+                uint32_t wd[NW], a[NW];
 #pragma unroll
-                    for (int t = 1; t <= r; t++) acc = acc + gk.k[r + t] * (p[-t] + p[t]);
-                }
-                sH[(q * OW + d) * HP + j] = acc;
+                for (int q2 = 0; q2 < NW; q2++) wd[q2] = wp[q2];
+#pragma unroll
+                for (int q2 = 0; q2 < NW; q2++)
+                    a[q2] = q2 + 1 < NW ? __builtin_amdgcn_alignbyte(wd[q2 + 1], wd[q2], woff) : wd[q2] >> (8 * woff);
+                auto tap = [&](int j) { return (float)((a[j >> 2] >> (8 * (j & 3))) & 255u); };
+                acc = gk.k[R] * tap(R);
+#pragma unroll
+                for (int t = 1; t <= R; t++) acc = acc + gk.k[R + t] * (tap(R - t) + tap(R + t));
+            } else if (R > 0) {
+                acc = gk.k[r] * (float)row[cx];
+#pragma unroll
+                for (int t = 1; t <= R; t++) acc = acc + gk.k[R + t] * ((float)row[xm[t - 1]] + (float)row[xp[t - 1]]);
+            } else if (interior) {
+                acc = gk.k[r] * (float)row[cx];
+                for (int t = 1; t <= r; t++) acc = acc + gk.k[r + t] * ((float)row[cx - t] + (float)row[cx + t]);
+            } else {
+                acc = gk.k[r] * (float)row[cx];
+                for (int t = 1; t <= r; t++)
+                    acc = acc + gk.k[r + t] * ((float)row[ffl_reflect101(cx - t, w)] + (float)row[ffl_reflect101(cx + t, w)]);
             }
         }
+        if (ybase + k < h) out[(size_t)y * lw * nq] = acc;
     }
-    __syncthreads();
+}
 
-    // V pass + lerps: one output per lane, output columns fastest (OW is a power of two)
-    for (int i = tid; i < OW * OH; i += 256) {
-        const int oy = i >> pt.lgOW, ox = i & (OW - 1);
-        if (ox >= nx || oy >= ny) continue;
-        float a1 = sFX[ox], b1 = sFY[oy], a0 = 1.f - a1, b0 = 1.f - b1;
-        const float *h0 = sH + (0 * OW + ox) * HP, *h1 = sH + (1 * OW + ox) * HP;
-        float t[2] = {0.f, 0.f};
+template <int R>
+__global__ __launch_bounds__(256) void k_pyr_v(const float *__restrict__ tmp, size_t tmp_stride, int w, int h, int lw,
+                                               int lh, int nq, double sx, double sy, GaussKernel gk,
+                                               float *__restrict__ I, size_t I_stride) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), u = blockIdx.z;
+    if (dx >= lw) return;
+    const int r = R > 0 ? R : (gk.ksize >> 1);
+    int x0, x1;
+    float a1;
+    ffl_resize_coord(dx, w, sx, x0, x1, a1);
+    const float a0 = 1.f - a1;
+    const size_t pitch = (size_t)lw * nq;
+    const float *col = tmp + (size_t)u * tmp_stride + (size_t)dx * nq;  // [row * pitch + q]
+    // 64 x (4 * ROWS) outputs per workgroup; fixed trip count + clamped rows so that the loop unrolls
+    // and every row's loads are in flight together
+    constexpr int ROWS = ffl_pyr_vrows(R);
 #pragma unroll
-        for (int qy = 0; qy < 2; qy++) {
-            if (qy == 1 && b1 == 0.f) break;
-            int cy = (qy ? sY1[oy] : sY0[oy]) - ys;
-            float v0 = gk.k[r] * h0[cy];
+    for (int k = 0; k < ROWS; k++) {
+    const int dyy = blockIdx.y * (4 * ROWS) + (threadIdx.x >> 6) + 4 * k;
+    const int dy = min(dyy, lh - 1);
+    int y0, y1;
+    float b1;
+    ffl_resize_coord(dy, h, sy, y0, y1, b1);
+    const float b0 = 1.f - b1;
+    float t[2] = {0.f, 0.f};
 #pragma unroll
-            for (int j = 1; j <= r; j++) v0 = v0 + gk.k[r + j] * (h0[cy - j] + h0[cy + j]);
-            float v1 = 0.f;
-            if (a1 != 0.f) {
-                v1 = gk.k[r] * h1[cy];
+    for (int qy = 0; qy < 2; qy++) {
+        if (qy == 1 && b1 == 0.f) break;
+        const int cy = qy ? y1 : y0;
+        const bool interior = cy >= r && cy + r < h;
+        float v[2] = {0.f, 0.f};
 #pragma unroll
-                for (int j = 1; j <= r; j++) v1 = v1 + gk.k[r + j] * (h1[cy - j] + h1[cy + j]);
+        for (int q = 0; q < 2; q++) {
+            if (q == 1 && a1 == 0.f) break;
+            const float *p = col + q;
+            float acc = gk.k[r] * p[(size_t)cy * pitch];
+            if (interior) {
+#pragma unroll
+                for (int j = 1; j <= r; j++)
+                    acc = acc + gk.k[r + j] * (p[(size_t)(cy - j) * pitch] + p[(size_t)(cy + j) * pitch]);
+            } else {
+#pragma unroll
+                for (int j = 1; j <= r; j++)
+                    acc = acc + gk.k[r + j] * (p[(size_t)ffl_reflect101(cy - j, h) * pitch] +
+                                               p[(size_t)ffl_reflect101(cy + j, h) * pitch]);
             }
-            t[qy] = v0 * a0 + v1 * a1;
+            v[q] = acc;
         }
-        I[(size_t)u * I_stride + (size_t)(dy0 + oy) * lw + dx0 + ox] = t[0] * b0 + t[1] * b1;
+        t[qy] = v[0] * a0 + v[1] * a1;
+    }
+    if (dyy < lh) I[(size_t)u * I_stride + (size_t)dy * lw + dx] = t[0] * b0 + t[1] * b1;
     }
 }
 
-// host copy of the device coordinate rule, used to size the staged window exactly
-static void host_resize_coord(int d, int src, int dst, int &i0, int &i1) {
-    double scale = (double)src / dst;
-    float fx = (float)((d + 0.5) * scale - 0.5);
-    int sx = (int)floorf(fx);
-    if (sx < 0) sx = 0;
-    if (sx >= src - 1) sx = src - 1;
-    i0 = sx;
-    i1 = sx + 1 < src ? sx + 1 : src - 1;
+// Fused form for the two fine levels of every BASELINE size: 3-tap blur (R = 1) with an exact S = 1
+// (level 0) or S = 2 (level 1) decimation.  One lane produces FROWS consecutive output rows of one
+// output column: the S*FROWS + 2 source rows are fetched word-wise once, blurred horizontally in
+// registers, then combined vertically -- no intermediate plane, same operations in the same order as
+// k_pyr_h + k_pyr_v (for S = 2 the lerp weights are exactly 0.5, for S = 1 the lerps are identities).
+#define FFL_PYR_FROWS 4
+template <int S>
+__global__ __launch_bounds__(256) void k_pyr_fused3(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
+                                                    int w, int h, int lw, int lh, GaussKernel gk,
+                                                    float *__restrict__ I, size_t I_stride) {
+    constexpr int NR = S * FFL_PYR_FROWS + 2;  // source rows per lane
+    const int dx = blockIdx.x * 256 + threadIdx.x, u = blockIdx.z;
+    if (dx >= lw) return;
+    const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
+    const int cx = S * dx;                       // first sampled column; S == 2 also samples cx + 1
+    const int first = cx - 1, woff = first & 3, wbase = first - woff;
+    const bool wide = first >= 0 && cx + S < w && (w & 3) == 0;  // taps cx-1 .. cx+S inside the row
+    const float k0 = gk.k[1], k1 = gk.k[2];
+    const int dy0 = blockIdx.y * FFL_PYR_FROWS;
+    float H0[NR], H1[NR];
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const int sy = ffl_reflect101(min(S * dy0 - 1 + j, h + 1), h);  // rows past the image are never used
+        const uint8_t *row = img + (size_t)sy * w;
+        float b[S + 2];
+        if (wide) {
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(row + wbase);
+            const uint32_t lo = wp[0], hi = wp[1];
+            const uint32_t a = __builtin_amdgcn_alignbyte(hi, lo, woff);  // bytes first .. first+3
+#pragma unroll
+            for (int t = 0; t < S + 2; t++) b[t] = (float)((a >> (8 * t)) & 255u);
+        } else {
+#pragma unroll
+            for (int t = 0; t < S + 2; t++) b[t] = (float)row[ffl_reflect101(first + t, w)];
+        }
+        H0[j] = k0 * b[1] + k1 * (b[0] + b[2]);
+        H1[j] = S == 2 ? k0 * b[2] + k1 * (b[1] + b[3]) : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < FFL_PYR_FROWS; o++) {
+        const int dy = dy0 + o;
+        if (dy >= lh) break;
+        const int c = S * o + 1;  // local index of source row S*dy
+        float out;
+        if (S == 1) {
+            const float v00 = k0 * H0[c] + k1 * (H0[c - 1] + H0[c + 1]);
+            out = (v00 * 1.f + 0.f * 0.f) * 1.f + 0.f * 0.f;
+        } else {
+            const float v00 = k0 * H0[c] + k1 * (H0[c - 1] + H0[c + 1]);
+            const float v01 = k0 * H1[c] + k1 * (H1[c - 1] + H1[c + 1]);
+            const float v10 = k0 * H0[c + 1] + k1 * (H0[c] + H0[c + 2]);
+            const float v11 = k0 * H1[c + 1] + k1 * (H1[c] + H1[c + 2]);
+            const float t0 = v00 * 0.5f + v01 * 0.5f, t1 = v10 * 0.5f + v11 * 0.5f;
+            out = t0 * 0.5f + t1 * 0.5f;
+        }
+        I[(size_t)u * I_stride + (size_t)dy * lw + dx] = out;
+    }
 }
 
-static int max_span(int src, int dst, int tile, int r) {
-    int best = 0;
-    for (int d0 = 0; d0 < dst; d0 += tile) {
-        int a0, a1, b0, b1;
-        host_resize_coord(d0, src, dst, a0, a1);
-        host_resize_coord(d0 + tile < dst ? d0 + tile - 1 : dst - 1, src, dst, b0, b1);
-        int span = b1 - a0 + 1 + 2 * r;
-        if (span > best) best = span;
-    }
-    return best;
-}
+size_t ffl_pyr_tmp_floats(int w, int h, int lw) { return (size_t)h * lw * (lw != w ? 2 : 1); }
 
 void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, int lw, int lh,
-                          GaussKernel gk, float *I, size_t I_stride, hipStream_t st) {
-    const int r = gk.ksize / 2;
-    // output tile: 64 wide at (near) full resolution, narrower as the decimation factor grows so the
-    // staged window stays within ~56 KB of LDS
-    PyrTile pt;
-    const double sx = (double)w / lw;
-    pt.OW = sx <= 2.5 ? 64 : (sx <= 5 ? 32 : 16);
-    pt.OH = sx <= 1.5 ? 16 : 8;
-    for (;;) {
-        pt.SW = max_span(w, lw, pt.OW, r) | 1;
-        pt.SH = max_span(h, lh, pt.OH, r);
-        size_t bytes = sizeof(float) * ((size_t)pt.SH * pt.SW + 2 * (size_t)pt.OW * (pt.SH | 1)) +
-                       sizeof(int) * 3 * (size_t)(pt.OW + pt.OH);
-        if (bytes <= 60 * 1024 || (pt.OW <= 8 && pt.OH <= 4)) {
-            pt.sx = (double)w / lw;
-            pt.sy = (double)h / lh;
-            pt.lgOW = 0;
-            while ((1 << pt.lgOW) < pt.OW) pt.lgOW++;
-            dim3 grid((lw + pt.OW - 1) / pt.OW, (lh + pt.OH - 1) / pt.OH, nU);
-#define FFL_PYR_LAUNCH(RR)                                                                                      \
-    hipLaunchKernelGGL(k_pyr_level<RR>, grid, dim3(256), bytes, st, gray_base, gray_stride, ut, w, h, lw, lh, gk, I, \
-                       I_stride, pt)
-            if (r == 1) FFL_PYR_LAUNCH(1);
-            else if (r == 4) FFL_PYR_LAUNCH(4);
-            else if (r == 9) FFL_PYR_LAUNCH(9);
-            else FFL_PYR_LAUNCH(0);
-#undef FFL_PYR_LAUNCH
-            return;
-        }
-        if (pt.OW > 8) pt.OW >>= 1;
-        else pt.OH >>= 1;
+                          GaussKernel gk, float *tmp, size_t tmp_stride, float *I, size_t I_stride, hipStream_t st) {
+    const int r = gk.ksize / 2, nq = lw != w ? 2 : 1;
+    const double sx = (double)w / lw, sy = (double)h / lh;
+    if (r == 1 && ((lw == w && lh == h) || (w == 2 * lw && h == 2 * lh))) {
+        dim3 grid((lw + 255) / 256, (lh + FFL_PYR_FROWS - 1) / FFL_PYR_FROWS, nU);
+        if (lw == w)
+            hipLaunchKernelGGL(k_pyr_fused3<1>, grid, dim3(256), 0, st, gray_base, gray_stride, ut, w, h, lw, lh, gk, I,
+                               I_stride);
+        else
+            hipLaunchKernelGGL(k_pyr_fused3<2>, grid, dim3(256), 0, st, gray_base, gray_stride, ut, w, h, lw, lh, gk, I,
+                               I_stride);
+        return;
     }
+#define FFL_PYR_LAUNCH(RR)                                                                                          \
+    do {                                                                                                            \
+        dim3 gv((lw + 63) / 64, (lh + 4 * ffl_pyr_vrows(RR) - 1) / (4 * ffl_pyr_vrows(RR)), nU);                    \
+        dim3 gh((lw * nq + 255) / 256, (h + ffl_pyr_rows(RR) - 1) / ffl_pyr_rows(RR), nU);                          \
+        hipLaunchKernelGGL(k_pyr_h<RR>, gh, dim3(256), 0, st, gray_base, gray_stride, ut, w, h, lw, nq, sx, gk, tmp, \
+                           tmp_stride);                                                                             \
+        hipLaunchKernelGGL(k_pyr_v<RR>, gv, dim3(256), 0, st, tmp, tmp_stride, w, h, lw, lh, nq, sx, sy, gk, I,      \
+                           I_stride);                                                                               \
+    } while (0)
+    if (r == 1) FFL_PYR_LAUNCH(1);
+    else if (r == 4) FFL_PYR_LAUNCH(4);
+    else if (r == 9) FFL_PYR_LAUNCH(9);
+    else FFL_PYR_LAUNCH(0);
+#undef FFL_PYR_LAUNCH
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -341,53 +389,72 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
                                                          int h, int pw, int ph, double usx, double usy) {
     int b, tile_x, tile_y;
     if (!ffl_tile_coord((w + 63) / 64, (h + 15) / 16, b, tile_x, tile_y)) return;
-    const int x = tile_x * 64 + (threadIdx.x & 63);
+    // two adjacent pixels per lane (8-byte R0 / M / 16-byte flow accesses): 32 lanes span the 64-wide
+    // tile, a wave covers 2 rows, the workgroup 8 rows per pass, 2 passes
+    const int x = tile_x * 64 + 2 * (threadIdx.x & 31);
     if (x >= w) return;
+    const bool second = x + 1 < w;
     const float *R0 = R + (size_t)pt.u0[b] * R_stride, *R1 = R + (size_t)pt.u1[b] * R_stride;
     float2 *flow = reinterpret_cast<float2 *>(pt.flow[b]);
     const float2 *prev = reinterpret_cast<const float2 *>(pt.prev[b]);
-    int x0 = 0, x1 = 0;
-    float a1 = 0.f;
-    if (UPSAMPLE) ffl_resize_coord(x, pw, usx, x0, x1, a1);
-    // 4 rows per lane, branch-free (rows past the image are clamped for the loads and only their
-    // stores are predicated) so that the loads of all 4 rows are in flight together.
-    float2 f[4];
-    int ys[4];
+    int xa0 = 0, xa1 = 0, xb0 = 0, xb1 = 0;
+    float aa1 = 0.f, ab1 = 0.f;
+    if (UPSAMPLE) {
+        ffl_resize_coord(x, pw, usx, xa0, xa1, aa1);
+        ffl_resize_coord(second ? x + 1 : x, pw, usx, xb0, xb1, ab1);
+    }
+    float *Mb = M + (size_t)b * M_stride;
+    // branch-free over the lane's 2 rows (clamped loads, predicated stores): all loads in flight together
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        ys[k] = tile_y * 16 + (threadIdx.x >> 6) + 4 * k;
-        const int y = min(ys[k], h - 1);
+    for (int k = 0; k < 2; k++) {
+        const int yy = tile_y * 16 + (threadIdx.x >> 5) + 8 * k;
+        const bool in = yy < h;
+        const int y = min(yy, h - 1);
         const size_t o = (size_t)y * w + x;
+        float2 f0, f1;
         if (UPSAMPLE) {
             int y0, y1;
             float b1;
             ffl_resize_coord(y, ph, usy, y0, y1, b1);
-            const float a0 = 1.f - a1, b0 = 1.f - b1;
-            const float2 p00 = prev[(size_t)y0 * pw + x0], p01 = prev[(size_t)y0 * pw + x1];
-            const float2 p10 = prev[(size_t)y1 * pw + x0], p11 = prev[(size_t)y1 * pw + x1];
+            const float b0 = 1.f - b1;
+            const float2 *r0p = prev + (size_t)y0 * pw, *r1p = prev + (size_t)y1 * pw;
             {
+                const float a1 = aa1, a0 = 1.f - a1;
+                const float2 p00 = r0p[xa0], p01 = r0p[xa1], p10 = r1p[xa0], p11 = r1p[xa1];
                 float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
-                f[k].x = (t0 * b0 + t1 * b1) * 2.0f;
+                f0.x = (t0 * b0 + t1 * b1) * 2.0f;
+                t0 = p00.y * a0 + p01.y * a1;
+                t1 = p10.y * a0 + p11.y * a1;
+                f0.y = (t0 * b0 + t1 * b1) * 2.0f;
             }
             {
-                float t0 = p00.y * a0 + p01.y * a1, t1 = p10.y * a0 + p11.y * a1;
-                f[k].y = (t0 * b0 + t1 * b1) * 2.0f;
+                const float a1 = ab1, a0 = 1.f - a1;
+                const float2 p00 = r0p[xb0], p01 = r0p[xb1], p10 = r1p[xb0], p11 = r1p[xb1];
+                float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
+                f1.x = (t0 * b0 + t1 * b1) * 2.0f;
+                t0 = p00.y * a0 + p01.y * a1;
+                t1 = p10.y * a0 + p11.y * a1;
+                f1.y = (t0 * b0 + t1 * b1) * 2.0f;
             }
-            if (ys[k] < h) flow[o] = f[k];
+            if (in) {
+                if (second) {
+                    ffl_f4u t;
+                    t.x = f0.x; t.y = f0.y; t.z = f1.x; t.w = f1.y;
+                    *reinterpret_cast<ffl_f4u *>(flow + o) = t;
+                } else {
+                    flow[o] = f0;
+                }
+            }
         } else {
-            f[k] = flow[o];
+            if (second) {
+                const ffl_f4u t = *reinterpret_cast<const ffl_f4u *>(flow + o);
+                f0 = make_float2(t.x, t.y);
+                f1 = make_float2(t.z, t.w);
+            } else {
+                f0 = f1 = flow[o];
+            }
         }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int y = min(ys[k], h - 1);
-        float m[5];
-        ffl_um_pixel(R0, R1, plane, w, h, x, y, f[k].x, f[k].y, m);
-        if (ys[k] < h) {
-            float *Mo = M + (size_t)b * M_stride + (size_t)y * w + x;
-#pragma unroll
-            for (int c = 0; c < 5; c++) Mo[c * plane] = m[c];
-        }
+        ffl_um_pair(R0, R1, plane, w, h, x, y, f0, f1, second, in, Mb);
     }
 }
 
@@ -522,27 +589,32 @@ __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *_
         sF4[(ty * TW + xg * PX) / 2 + 1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
     }
     __syncthreads();
-    const float2 *sF = reinterpret_cast<const float2 *>(sF4);
-    const int lx = tid & 63, x = x0 + lx;
+    // two adjacent pixels per lane: 16-byte flow stores, 8-byte R0 loads / M stores / R1 gathers --
+    // half the vector-memory instructions of a pixel-per-lane mapping (they, not bytes, bound this
+    // phase).  32 lanes span the tile row, the workgroup covers 8 rows per pass.
+    const int lx = 2 * (tid & 31), x = x0 + lx;
     if (x >= w) return;
-    // branch-free over the lane's TH/4 rows (clamped loads, predicated stores): all gathers in flight
+    const bool second = x + 1 < w;
+    float *Mo = Mout + (size_t)b * M_stride;
+    // branch-free over the lane's rows (clamped loads, predicated stores): all gathers in flight
 #pragma unroll
-    for (int k = 0; k < TH / 4; k++) {
-        const int ly = (tid >> 6) + 4 * k;
+    for (int k = 0; k < TH / 8; k++) {
+        const int ly = (tid >> 5) + 8 * k;
         const bool in = y0 + ly < h;
         const int y = min(y0 + ly, h - 1);
-        const float2 f = sF[ly * TW + lx];
+        const float4 ff = sF4[(ly * TW + lx) >> 1];
+        const float2 f0 = make_float2(ff.x, ff.y), f1 = make_float2(ff.z, ff.w);
         const size_t o = (size_t)y * w + x;
-        if (in) flow[o] = f;
-        if (UPDATE) {
-            float m[5];
-            ffl_um_pixel(R0, R1, plane, w, h, x, y, f.x, f.y, m);
-            if (in) {
-                float *Mo = Mout + (size_t)b * M_stride + o;
-#pragma unroll
-                for (int c = 0; c < 5; c++) Mo[c * plane] = m[c];
+        if (in) {
+            if (second) {
+                ffl_f4u t;
+                t.x = ff.x; t.y = ff.y; t.z = ff.z; t.w = ff.w;
+                *reinterpret_cast<ffl_f4u *>(flow + o) = t;
+            } else {
+                flow[o] = f0;
             }
         }
+        if (UPDATE) ffl_um_pair(R0, R1, plane, w, h, x, y, f0, f1, second, in, Mo);
     }
 }
 

@@ -114,8 +114,12 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 
-/* Process-wide tuning knobs (results do not depend on them):
- *   "blur_tile_h" = 8 | 16 | 32   rows of the 64-wide k_blur_solve LDS tile (BASELINE configs[2] sweep) */
+/* Process-wide tuning knobs (results never depend on them):
+ *   "blur_tile_h" = 8 | 16   rows of the 64-wide k_blur_solve LDS tile (BASELINE configs[2] sweep)
+ *   "lanes"       = 1..4     compute lanes (co-scheduled batches, each on its own stream and work
+ *                            buffers) of contexts created afterwards; default 2
+ *   "run_ahead"   = 0|1|2    schedule of the frame-only kernels: 0 serial (default), 1 run-ahead on a
+ *                            side stream, 2 fork/join over per-level side streams */
 int ffl_set_option(const char *name, int value);
 
 /* HIP-event timing of kernel classes: every launch of a class whose bit (1u << FFL_K_*) is set in
@@ -125,7 +129,7 @@ int ffl_profile_enable(ffl_ctx *ctx, unsigned class_mask);
 #define FFL_K_GRAY 0
 #define FFL_K_PYRAMID 1
 #define FFL_K_POLYEXP 2
-#define FFL_K_UPSAMPLE 3
+#define FFL_K_UPSAMPLE 3 /* reserved: the x2 flow upsample runs inside k_update_matrices */
 #define FFL_K_UPDATE_MATRICES 4
 #define FFL_K_BLUR_SOLVE 5
 #define FFL_K_PASS1 6
