@@ -315,15 +315,25 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, si
     const int x0 = blockIdx.x * PE_TW, y0 = blockIdx.y * PE_TH;
     const float *img = I + (size_t)u * I_stride;
 
-    for (int i = tid; i < (PE_TH + 2 * PE_N) * PE_LW; i += 256) {
-        int ly = i / PE_LW, lx = i - ly * PE_LW;
-        int gy = min(max(y0 + ly - PE_N, 0), h - 1), gx = min(max(x0 + lx - PE_N, 0), w - 1);
-        sI[ly][lx] = img[(size_t)gy * w + gx];
+    // fixed trip counts (+ a bounds predicate) so that the loops unroll: a rolled loop issues one
+    // global load, waits for it, stores it to LDS, and only then issues the next
+    constexpr int N_IN = (PE_TH + 2 * PE_N) * PE_LW, N_V = PE_TH * PE_LW, N_OUT = PE_TH * PE_TW;
+#pragma unroll
+    for (int it = 0; it < (N_IN + 255) / 256; it++) {
+        const int i = tid + 256 * it;
+        if (i < N_IN) {
+            int ly = i / PE_LW, lx = i - ly * PE_LW;
+            int gy = min(max(y0 + ly - PE_N, 0), h - 1), gx = min(max(x0 + lx - PE_N, 0), w - 1);
+            sI[ly][lx] = img[(size_t)gy * w + gx];
+        }
     }
     __syncthreads();
 
     // vertical part (float): rows are clamped because the tile was loaded with clamped rows
-    for (int i = tid; i < PE_TH * PE_LW; i += 256) {
+#pragma unroll
+    for (int it = 0; it < (N_V + 255) / 256; it++) {
+        const int i = tid + 256 * it;
+        if (i >= N_V) break;
         int ly = i / PE_LW, lx = i - ly * PE_LW;
         float c = sI[ly + PE_N][lx];
         float r0 = c * pc.g[0], r1 = 0.f, r2 = 0.f;
@@ -343,7 +353,9 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, si
 
     // horizontal part (double accumulators; the b2,b3,b5,b6 products are float products)
     float *out = R + (size_t)u * R_stride;
-    for (int i = tid; i < PE_TH * PE_TW; i += 256) {
+#pragma unroll
+    for (int it = 0; it < N_OUT / 256; it++) {
+        const int i = tid + 256 * it;
         int ly = i / PE_TW, lx = i - ly * PE_TW;
         int x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
