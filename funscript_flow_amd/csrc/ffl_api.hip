@@ -155,6 +155,8 @@ static void polyexp_prepare(PolyConsts *pc) {  // FarnebackPrepareGaussian(n = 5
         pc->g[x] = gg[x + n];
         pc->xg[x] = (float)(x * gg[x + n]);
         pc->xxg[x] = (float)(x * x * gg[x + n]);
+        pc->gd[x] = (double)pc->g[x];
+        pc->xxgd[x] = (double)pc->xxg[x];
     }
     double G[6][6];
     memset(G, 0, sizeof(G));

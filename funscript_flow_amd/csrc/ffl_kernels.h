@@ -20,6 +20,7 @@
 
 struct PolyConsts {
     float g[FFL_POLY_N + 1], xg[FFL_POLY_N + 1], xxg[FFL_POLY_N + 1];
+    double gd[FFL_POLY_N + 1], xxgd[FFL_POLY_N + 1];  // (double)g[k], (double)xxg[k]: widened once on the host
     double ig11, ig03, ig33, ig55;
 };
 

@@ -366,8 +366,8 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, si
         for (int k = 1; k <= PE_N; k++) {
             double tg = (double)(v0[k] + v0[-k]);
             g0 = pc.g[k];
-            b1 += tg * (double)g0;
-            b4 += tg * (double)pc.xxg[k];
+            b1 += tg * pc.gd[k];
+            b4 += tg * pc.xxgd[k];
             b2 += (double)((v0[k] - v0[-k]) * pc.xg[k]);
             b3 += (double)((v1[k] + v1[-k]) * g0);
             b6 += (double)((v1[k] - v1[-k]) * pc.xg[k]);

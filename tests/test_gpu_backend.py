@@ -134,6 +134,33 @@ def test_results_do_not_depend_on_batching_or_slots():
         assert np.array_equal(a[j], orc.farneback(fr[j], fr[j + 1]))
 
 
+def test_results_do_not_depend_on_schedule_options():
+    """Compute lanes (co-scheduled batches), the frame-expansion schedules and the LDS tile height are
+    speed knobs only: many small batches in flight on recycled frame/flow slots give identical bits."""
+    w, h = 192, 144
+    n = 21
+    fr = sine_translate_frames(n + 1, w, h, seed=33, amp=(2.0, 1.0), period=9)
+    want = None
+    try:
+        for lanes, run_ahead, tile in [(1, 0, 16), (2, 0, 16), (2, 1, 8), (3, 2, 16), (1, 1, 16)]:
+            _capi.set_option("lanes", lanes)
+            _capi.set_option("run_ahead", run_ahead)
+            _capi.set_option("blur_tile_h", tile)
+            with _capi.Context(w, h, max_batch=3, frame_slots=8, flow_slots=3 * 3 + 13) as ctx:
+                dots, recs = pipeline.PairEngine(ctx).process_chunk(fr)
+                last = ctx.download_flow((n - 1) % ctx.flow_slots)
+            got = (np.array(dots), [tuple(r) for r in recs], last)
+            if want is None:
+                want = got
+                assert np.array_equal(last, orc.farneback(fr[n - 1], fr[n]))
+            else:
+                assert np.array_equal(got[0], want[0]) and got[1] == want[1] and np.array_equal(got[2], want[2])
+    finally:
+        _capi.set_option("lanes", 2)
+        _capi.set_option("run_ahead", 0)
+        _capi.set_option("blur_tile_h", 16)
+
+
 @pytest.mark.parametrize("w,h", [(1920, 1080), (3840, 2160)])
 def test_full_size_pair_bit_exact_and_properties(w, h):
     fr = sine_translate_frames(3, w, h, seed=1)
