@@ -13,6 +13,11 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no binaries (they are git-ignored): build them once, exactly as build() does
+    lib = os.path.join(ROOT, "funscript_flow_amd", "csrc", "libffl_hip.so")
+    if not os.path.exists(lib) or not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        import __graft_entry__
+        __graft_entry__.build()
 
 
 @pytest.fixture(scope="session")
