@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libffl_hip.so")
 
 FFL_OK = 0
-FFL_MAX_BATCH = 32
+FFL_MAX_BATCH = 64
 # kernel classes of ffl_profile_read (index 3 is reserved: the x2 flow upsample is fused into k_update_matrices)
 KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "(reserved)", "k_update_matrices", "k_blur_solve",
                   "k_pass1", "k_radial"]

@@ -12,7 +12,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define FFL_MAXB 32
+#define FFL_MAXB 64
 #define FFL_MAXU (2 * FFL_MAXB)
 #define FFL_POLY_N 5
 #define FFL_WIN 15
