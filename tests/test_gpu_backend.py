@@ -191,6 +191,31 @@ def test_full_size_pair_bit_exact_and_properties(w, h):
             assert abs(got - want) <= 0.15 * abs(want) + 0.05
 
 
+def test_stereo_frame_split_per_eye_via_strides():
+    """BASELINE configs[4] shape (VR side-by-side stereo, each eye an independent image): the
+    eyes of a (H, 2H) frame are uploaded straight out of the full frame through the row stride of
+    ffl_upload_frame -- no host-side copy -- and each eye's pair matches the oracle."""
+    eh = 160
+    full = sine_translate_frames(2, 2 * eh, eh, seed=17, amp=(3.0, 1.0), period=5)      # (2, eh, 2*eh)
+    full_bgr = gray_to_bgr(full)
+    with _capi.Context(eh, eh, max_batch=2, frame_slots=4, flow_slots=4) as ctx:
+        for eye in (0, 1):
+            for t in (0, 1):
+                view = full[t][:, eye * eh:(eye + 1) * eh]                           # non-contiguous view
+                assert not view.flags["C_CONTIGUOUS"]
+                ctx.upload_frame(2 * eye + t, view)
+        ctx.flow_pairs([0, 2], [1, 3], [0, 1])
+        for eye in (0, 1):
+            ref = orc.farneback(np.ascontiguousarray(full[0][:, eye * eh:(eye + 1) * eh]),
+                                np.ascontiguousarray(full[1][:, eye * eh:(eye + 1) * eh]))
+            assert np.array_equal(ctx.download_flow(eye), ref)
+        # same through the 3-channel path
+        for t in (0, 1):
+            ctx.upload_frame(t, full_bgr[t][:, eh:2 * eh])
+        ctx.flow_pairs([0], [1], [2])
+        assert np.array_equal(ctx.download_flow(2), ctx.download_flow(1))
+
+
 def test_ragged_and_minimum_sizes():
     """Odd sizes (no 4-pixel alignment), tiles cut by every border, fewer pyramid levels."""
     for (w, h) in [(67, 45), (131, 70), (257, 255), (64, 33)]:
