@@ -15,8 +15,8 @@ KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "(reserved)", "k_update_
                   "k_pass1", "k_radial"]
 
 # every symbol include/ffl.h declares (tests check that the library exports all of them)
-EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "ffl_upload_frame", "ffl_flow_pairs",
-           "ffl_pass1_result", "ffl_radial", "ffl_download_flow", "ffl_upload_flow", "ffl_submit_pair", "ffl_sync",
+EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "ffl_upload_frame", "ffl_upload_frames", "ffl_flow_pairs",
+           "ffl_pass1_result", "ffl_pass1_results", "ffl_radial", "ffl_download_flow", "ffl_upload_flow", "ffl_submit_pair", "ffl_sync",
            "ffl_num_levels", "ffl_level_size", "ffl_debug_pair", "ffl_set_option", "ffl_profile_enable",
            "ffl_profile_read", "ffl_kernel_name"]
 
@@ -45,9 +45,12 @@ def load():
     L.ffl_last_error.argtypes = [vp]
     L.ffl_last_error.restype = C.c_char_p
     L.ffl_upload_frame.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t]
+    L.ffl_upload_frames.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.ffl_flow_pairs.argtypes = [vp, C.c_int, ip, ip, ip, C.c_int]
     L.ffl_pass1_result.argtypes = [vp, C.c_int, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_float), C.POINTER(C.c_float), ip]
+    L.ffl_pass1_results.argtypes = [vp, C.c_int, ip, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                    C.POINTER(C.c_float), C.POINTER(C.c_float), ip]
     L.ffl_radial.argtypes = [vp, C.c_int, ip, dp, dp, ip, C.c_int, dp]
     L.ffl_download_flow.argtypes = [vp, C.c_int, vp]
     L.ffl_upload_flow.argtypes = [vp, C.c_int, vp, C.c_int]
@@ -126,6 +129,18 @@ class Context:
         self._chk(self.L.ffl_upload_frame(self._h, fslot, frame.ctypes.data, frame.shape[1], frame.shape[0], ch,
                                           frame.strides[0]))
 
+    def upload_frames(self, first_slot, frames):
+        """frames: sequence of equally shaped uint8 frames -> consecutive slots, one H2D transfer."""
+        fr = [f if (f.strides[-1] == 1 and (f.ndim == 2 or f.strides[1] == f.shape[2])) else np.ascontiguousarray(f)
+              for f in frames]
+        f0 = fr[0]
+        ch = 1 if f0.ndim == 2 else f0.shape[2]
+        if any(f.dtype != np.uint8 or f.shape != f0.shape or f.strides[0] != f0.strides[0] for f in fr):
+            raise FFLError("upload_frames needs uint8 frames of one shape and row stride")
+        ptrs = (C.c_void_p * len(fr))(*[f.ctypes.data for f in fr])
+        self._chk(self.L.ffl_upload_frames(self._h, first_slot, len(fr), ptrs, f0.shape[1], f0.shape[0], ch,
+                                           f0.strides[0]))
+
     def flow_pairs(self, fslot0, fslot1, flow_slots, pov_mode=False):
         n = len(flow_slots)
         self._chk(self.L.ffl_flow_pairs(self._h, n, _iarr(fslot0), _iarr(fslot1), _iarr(flow_slots), int(bool(pov_mode))))
@@ -142,6 +157,14 @@ class Context:
         self._chk(self.L.ffl_pass1_result(self._h, flow_slot, float(cut_threshold), C.byref(x), C.byref(y), C.byref(v),
                                           C.byref(mm), C.byref(c)))
         return x.value, y.value, np.float32(v.value), np.float32(mm.value), bool(c.value)
+
+    def pass1_results(self, flow_slots, cut_threshold=7.0):
+        """ffl_pass1_results: the records of many slots with one call (list of pass1_result tuples)."""
+        n = len(flow_slots)
+        x, y, c = (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int * n)()
+        v, mm = (C.c_float * n)(), (C.c_float * n)()
+        self._chk(self.L.ffl_pass1_results(self._h, n, _iarr(flow_slots), float(cut_threshold), x, y, v, mm, c))
+        return [(x[i], y[i], np.float32(v[i]), np.float32(mm[i]), bool(c[i])) for i in range(n)]
 
     def radial(self, flow_slots, centers, is_cut, pov_mode=False):
         n = len(flow_slots)

@@ -71,8 +71,11 @@ struct ffl_ctx {
     // frames
     uint8_t *d_gray = nullptr;        // [n_fslots][N]
     uint8_t *d_bgr = nullptr;         // [n_fslots][3N] staging for 3-channel uploads
-    uint8_t *h_stage = nullptr;       // pinned [n_fslots][3N]
-    std::vector<hipEvent_t> ev_uploaded;
+    uint8_t *h_stage_gray = nullptr;  // pinned [n_fslots][N]   (separate, so that runs of slots are contiguous)
+    uint8_t *h_stage_bgr = nullptr;   // pinned [n_fslots][3N]
+    std::vector<hipEvent_t> ev_uploaded;  // handles into up_ring (one event per upload call), or null
+    hipEvent_t up_ring[2 * FFL_EV_RING] = {nullptr};
+    unsigned up_next = 0;
     std::vector<hipEvent_t> ev_last_use;  // [frame slot * n_lanes + lane]: handle of the last batch event, or null
     std::vector<char> frame_valid;
     hipEvent_t post_ring[FFL_EV_RING] = {nullptr};  // events of ffl_upload_flow (s_post)
@@ -279,10 +282,11 @@ void ffl_destroy(ffl_ctx *c) {
     if (c->s_post) hipStreamSynchronize(c->s_post);
     if (c->s_copy) hipStreamSynchronize(c->s_copy);
     prof_collect(c);
-    for (auto e : c->ev_uploaded) hipEventDestroy(e);
+    for (auto e : c->up_ring)
+        if (e) hipEventDestroy(e);
     for (auto e : c->post_ring)
         if (e) hipEventDestroy(e);
-    hipFree(c->d_gray); hipFree(c->d_bgr); hipHostFree(c->h_stage);
+    hipFree(c->d_gray); hipFree(c->d_bgr); hipHostFree(c->h_stage_gray); hipHostFree(c->h_stage_bgr);
     for (auto &L : c->lanes) {
         hipFree(L.d_I); hipFree(L.d_T); hipFree(L.d_R); hipFree(L.d_M[0]); hipFree(L.d_M[1]);
         hipFree(L.d_flowA); hipFree(L.d_flowB); hipFree(L.d_pkey); hipFree(L.d_psum);
@@ -343,7 +347,8 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     const int maxU = 2 * max_batch;
     CCHK(hipMalloc(&c->d_gray, (size_t)n_frame_slots * N + 16));  // +16: k_pyr_h fetches taps as aligned words
     CCHK(hipMalloc(&c->d_bgr, (size_t)n_frame_slots * N * 3));
-    CCHK(hipHostMalloc(&c->h_stage, (size_t)n_frame_slots * N * 3, hipHostMallocDefault));
+    CCHK(hipHostMalloc(&c->h_stage_gray, (size_t)n_frame_slots * N, hipHostMallocDefault));
+    CCHK(hipHostMalloc(&c->h_stage_bgr, (size_t)n_frame_slots * N * 3, hipHostMallocDefault));
     c->p1_blocks = ffl_pass1_blocks(width, height);
     c->lanes.resize(g_num_lanes);
     for (auto &L : c->lanes) {
@@ -378,10 +383,10 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     CCHK(hipMalloc(&c->d_ppkey, sizeof(unsigned long long) * c->p1_blocks));
     CCHK(hipHostMalloc(&c->h_radial, sizeof(double) * FFL_MAXB, hipHostMallocMapped));
     CCHK(hipHostGetDevicePointer((void **)&c->d_radial, c->h_radial, 0));
-    c->ev_uploaded.resize(n_frame_slots);
+    c->ev_uploaded.assign(n_frame_slots, nullptr);
     c->ev_last_use.assign((size_t)n_frame_slots * g_num_lanes, nullptr);  // handles into the lanes' rings
     c->frame_valid.assign(n_frame_slots, 0);
-    for (int i = 0; i < n_frame_slots; i++) CCHK(hipEventCreateWithFlags(&c->ev_uploaded[i], hipEventDisableTiming));
+    for (auto &e : c->up_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : c->post_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->ev_slot_done.assign(n_flow_slots, nullptr);                        // handles, set when a slot is queued
     c->slot_state.assign(n_flow_slots, 0);
@@ -400,42 +405,61 @@ int ffl_level_size(const ffl_ctx *c, int level, int *out_wh) {
     return FFL_OK;
 }
 
+// n frames into the consecutive frame slots first..first+n-1: host copies into pinned staging, then ONE
+// H2D transfer (+ one BGR->gray launch) and ONE event for the whole run -- at 256x256 the per-frame
+// runtime calls of a frame-at-a-time upload cost more than the copy itself.
+int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames, int width, int height, int channels,
+                      ptrdiff_t stride_bytes) {
+    if (!c) return FFL_ERR_INVALID;
+    if (!frames || n < 1 || first < 0 || first + n > c->n_fslots)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames: bad frame slot range %d..%d", first, first + n - 1);
+    if (width != c->w || height != c->h)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames: frame is %dx%d, context is %dx%d", width, height, c->w, c->h);
+    if (channels != 1 && channels != 3)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames: channels must be 1 (gray) or 3 (BGR), got %d", channels);
+    if (stride_bytes < (ptrdiff_t)width * channels)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames: stride %td < row bytes %d", stride_bytes, width * channels);
+    for (int i = 0; i < n; i++)
+        if (!frames[i]) return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames: frame %d is NULL", i);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t N = c->N, row = (size_t)width * channels, fbytes = N * channels;
+    uint8_t *stage0 = (channels == 1 ? c->h_stage_gray : c->h_stage_bgr) + (size_t)first * fbytes;
+    for (int i = 0; i < n; i++) {
+        const int fs = first + i;
+        // the previous transfer out of this slot's staging areas must have left the host buffer
+        if (c->ev_uploaded[fs]) HIPCHK(c, hipEventSynchronize(c->ev_uploaded[fs]));
+        uint8_t *stage = stage0 + (size_t)i * fbytes;
+        const uint8_t *data = frames[i];
+        if ((size_t)stride_bytes == row) memcpy(stage, data, row * height);
+        else
+            for (int y = 0; y < height; y++) memcpy(stage + (size_t)y * row, data + (ptrdiff_t)y * stride_bytes, row);
+        // the device copy of this slot may still be read by batches queued on any lane
+        for (size_t l = 0; l < c->lanes.size(); l++) {
+            hipEvent_t e = c->ev_last_use[(size_t)fs * c->lanes.size() + l];
+            if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
+        }
+    }
+    uint8_t *gray = c->d_gray + (size_t)first * N;
+    if (channels == 1) {
+        HIPCHK(c, hipMemcpyAsync(gray, stage0, N * n, hipMemcpyHostToDevice, c->s_copy));
+    } else {
+        uint8_t *bgr = c->d_bgr + (size_t)first * N * 3;
+        HIPCHK(c, hipMemcpyAsync(bgr, stage0, N * 3 * n, hipMemcpyHostToDevice, c->s_copy));
+        ProfScope ps(c, FFL_K_GRAY, c->s_copy);
+        ffl_launch_gray(bgr, gray, (int)(N * n), c->s_copy);
+    }
+    hipEvent_t ev = c->up_ring[c->up_next++ % (2 * FFL_EV_RING)];
+    HIPCHK(c, hipEventRecord(ev, c->s_copy));
+    for (int i = 0; i < n; i++) {
+        c->ev_uploaded[first + i] = ev;
+        c->frame_valid[first + i] = 1;
+    }
+    return FFL_OK;
+}
+
 int ffl_upload_frame(ffl_ctx *c, int fslot, const uint8_t *data, int width, int height, int channels,
                      ptrdiff_t stride_bytes) {
-    if (!c) return FFL_ERR_INVALID;
-    if (!data || fslot < 0 || fslot >= c->n_fslots)
-        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frame: bad frame slot %d", fslot);
-    if (width != c->w || height != c->h)
-        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frame: frame is %dx%d, context is %dx%d", width, height, c->w, c->h);
-    if (channels != 1 && channels != 3)
-        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frame: channels must be 1 (gray) or 3 (BGR), got %d", channels);
-    if (stride_bytes < (ptrdiff_t)width * channels)
-        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frame: stride %td < row bytes %d", stride_bytes, width * channels);
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t N = c->N, row = (size_t)width * channels;
-    uint8_t *stage = c->h_stage + (size_t)fslot * N * 3;
-    // the previous transfer out of this staging area must have left the host buffer
-    if (c->frame_valid[fslot]) HIPCHK(c, hipEventSynchronize(c->ev_uploaded[fslot]));
-    if ((size_t)stride_bytes == row) memcpy(stage, data, row * height);
-    else
-        for (int y = 0; y < height; y++) memcpy(stage + (size_t)y * row, data + (ptrdiff_t)y * stride_bytes, row);
-    // the device copy of this slot may still be read by batches queued on any lane
-    for (size_t l = 0; l < c->lanes.size(); l++) {
-        hipEvent_t e = c->ev_last_use[(size_t)fslot * c->lanes.size() + l];
-        if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
-    }
-    uint8_t *gray = c->d_gray + (size_t)fslot * N;
-    if (channels == 1) {
-        HIPCHK(c, hipMemcpyAsync(gray, stage, N, hipMemcpyHostToDevice, c->s_copy));
-    } else {
-        uint8_t *bgr = c->d_bgr + (size_t)fslot * N * 3;
-        HIPCHK(c, hipMemcpyAsync(bgr, stage, N * 3, hipMemcpyHostToDevice, c->s_copy));
-        ProfScope ps(c, FFL_K_GRAY, c->s_copy);
-        ffl_launch_gray(bgr, gray, (int)N, c->s_copy);
-    }
-    HIPCHK(c, hipEventRecord(c->ev_uploaded[fslot], c->s_copy));
-    c->frame_valid[fslot] = 1;
-    return FFL_OK;
+    return ffl_upload_frames(c, fslot, 1, &data, width, height, channels, stride_bytes);
 }
 
 struct DebugCapture {
@@ -642,6 +666,19 @@ int ffl_pass1_result(ffl_ctx *c, int slot, float cut_threshold, int32_t *x, int3
     if (div_val) *div_val = r.div_val;
     if (mean_mag) *mean_mag = mm;
     if (cut) *cut = mm > cut_threshold ? 1 : 0;
+    return FFL_OK;
+}
+
+int ffl_pass1_results(ffl_ctx *c, int n, const int *slots, float cut_threshold, int32_t *x, int32_t *y, float *div_val,
+                      float *mean_mag, int *cut) {
+    if (!c) return FFL_ERR_INVALID;
+    if (n < 0 || (n > 0 && !slots)) return set_err(c, FFL_ERR_INVALID, "ffl_pass1_results: bad arguments");
+    for (int i = 0; i < n; i++) {
+        int rc = ffl_pass1_result(c, slots[i], cut_threshold, x ? x + i : nullptr, y ? y + i : nullptr,
+                                  div_val ? div_val + i : nullptr, mean_mag ? mean_mag + i : nullptr,
+                                  cut ? cut + i : nullptr);
+        if (rc) return rc;
+    }
     return FFL_OK;
 }
 

@@ -64,19 +64,24 @@ class PairEngine:
 
         def enqueue(k):
             js = list(range(k, min(k + B, pair_hi)))
-            for i in range(js[0], js[-1] + 2):
-                if uploaded.get(fslot(i)) != i:
-                    ctx.upload_frame(fslot(i), frames[i])
+            new = [i for i in range(js[0], js[-1] + 2) if uploaded.get(fslot(i)) != i]
+            while new:  # runs of consecutive frame slots go up with one H2D transfer each
+                run = [new[0]]
+                while len(run) < len(new) and new[len(run)] == run[-1] + 1 and fslot(new[len(run)]) == fslot(run[-1]) + 1:
+                    run.append(new[len(run)])
+                ctx.upload_frames(fslot(run[0]), [frames[i] for i in run])
+                for i in run:
                     uploaded[fslot(i)] = i
+                new = new[len(run):]
             ctx.flow_pairs([fslot(j) for j in js], [fslot(j + 1) for j in js],
                            [(j - pair_lo) % ctx.flow_slots for j in js], pov_mode)
             return js
 
         def collect(js):
-            for j in js:
-                recs[j - pair_lo] = ctx.pass1_result((j - pair_lo) % ctx.flow_slots, cut_threshold)
+            got = ctx.pass1_results([(j - pair_lo) % ctx.flow_slots for j in js], cut_threshold)  # one call per batch
+            recs[js[0] - pair_lo:js[-1] + 1 - pair_lo] = got
             if on_batch:
-                on_batch(js)
+                on_batch(js, got)
 
         pending = None
         for k in range(pair_lo, pair_hi, B):
@@ -95,28 +100,27 @@ class PairEngine:
         if n < 1:
             return np.zeros(0), []
         dots = np.zeros(n, np.float64)
-        pos = np.zeros((n, 2), np.int64)
-        cuts = np.zeros(n, bool)
+        psum = np.zeros((n + 1, 2), np.int64)  # prefix sums of pos_center: window means are exact integer
+        cuts = np.zeros(n, bool)               # sums / counts, bit-identical to np.mean over the window
         state = {"known": 0, "done": 0}
         recs_all = [None] * n
 
         def finalize(limit):
             while state["done"] < limit:
-                js = list(range(state["done"], min(state["done"] + B, limit)))
-                cs = []
-                for j in js:
-                    lo, hi = max(0, j - SMOOTH_RADIUS), min(n, j + SMOOTH_RADIUS + 1)
-                    cs.append(np.mean(pos[lo:hi], axis=0))
-                out = ctx.radial([j % ctx.flow_slots for j in js], cs, [cuts[j] for j in js], pov_mode)
-                dots[js[0]:js[-1] + 1] = out
-                state["done"] = js[-1] + 1
+                j0, j1 = state["done"], min(state["done"] + B, limit)
+                js = np.arange(j0, j1)
+                lo, hi = np.maximum(0, js - SMOOTH_RADIUS), np.minimum(n, js + SMOOTH_RADIUS + 1)
+                cs = (psum[hi] - psum[lo]) / (hi - lo)[:, None]
+                out = ctx.radial(list(js % ctx.flow_slots), cs, cuts[j0:j1], pov_mode)
+                dots[j0:j1] = out
+                state["done"] = j1
 
-        def on_batch(js):
-            for j in js:
-                r = ctx.pass1_result(j % ctx.flow_slots, cut_threshold)
-                recs_all[j] = r
-                pos[j] = (r[0], r[1])
-                cuts[j] = r[4]
+        def on_batch(js, got):
+            j0 = js[0]
+            recs_all[j0:js[-1] + 1] = got
+            p = np.array([(r[0], r[1]) for r in got], np.int64)
+            psum[j0 + 1:js[-1] + 2] = psum[j0] + np.cumsum(p, axis=0)
+            cuts[j0:js[-1] + 1] = [r[4] for r in got]
             state["known"] = js[-1] + 1
             finalize(n if state["known"] == n else max(0, state["known"] - SMOOTH_RADIUS))
 

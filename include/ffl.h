@@ -68,6 +68,11 @@ const char *ffl_last_error(const ffl_ctx *ctx);
 int ffl_upload_frame(ffl_ctx *ctx, int fslot, const uint8_t *data, int width, int height, int channels,
                      ptrdiff_t stride_bytes);
 
+/* The same for n frames going to the consecutive slots first_slot .. first_slot+n-1, with one H2D transfer
+ * (and one gray-conversion launch) for the whole run: the batched small-image path. */
+int ffl_upload_frames(ffl_ctx *ctx, int first_slot, int n, const uint8_t *const *frames, int width, int height,
+                      int channels, ptrdiff_t stride_bytes);
+
 /* Queue Farneback flow + pass-1 reductions for n pairs: pair i = (frame fslot0[i], frame fslot1[i])
  * -> flow slot flow_slots[i].  Frames shared between pairs of the batch are expanded once.
  * pov_mode != 0 skips the divergence argmax (FF:880-882).  Asynchronous. */
@@ -77,6 +82,10 @@ int ffl_flow_pairs(ffl_ctx *ctx, int n, const int *fslot0, const int *fslot1, co
  * (x, y) = pos_center, div_val = val_pos, mean_mag, cut = mean_mag > cut_threshold. */
 int ffl_pass1_result(ffl_ctx *ctx, int flow_slot, float cut_threshold, int32_t *x, int32_t *y, float *div_val,
                      float *mean_mag, int *cut);
+
+/* The same for n slots with one call (arrays of n elements; any output array may be NULL). */
+int ffl_pass1_results(ffl_ctx *ctx, int n, const int *flow_slots, float cut_threshold, int32_t *x, int32_t *y,
+                      float *div_val, float *mean_mag, int *cut);
 
 /* radial_motion_weighted for n resident flow fields (FF:761-785); out[i] is float64.
  * is_cut[i] != 0 yields 0.0 without touching the device.  Synchronous. */
