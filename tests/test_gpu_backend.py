@@ -104,6 +104,27 @@ def test_end_to_end_funscript_matches_reference(golden_dir):
     assert actions == meta["funscript"]["actions"]
 
 
+def test_config0_clip_640x360_to_funscript(tmp_path):
+    """BASELINE configs[0] at native resolution: a 64-frame 640x360 sine-translate clip -> .funscript on the
+    HIP path equals the same host chain fed by the CPU oracle (flow, argmax, cut, radial), action for action."""
+    from funscript_flow_amd import postchain
+    w, h, n, fps = 640, 360, 64, 30.0
+    frames = sine_translate_frames(n, w, h, seed=0, amp=(4.0, 4.0), period=16, zoom=0.03)
+    params = {"detrend_window": 2.0, "norm_window": 3.0, "batch_size": 3000, "keyframe_reduction": True,
+              "pov_mode": False}
+    with _capi.Context(w, h, max_batch=8, frame_slots=18, flow_slots=37) as ctx:
+        got = pipeline.frames_to_actions(pipeline.PairEngine(ctx), frames, fps, params)
+    flows = [orc.farneback(frames[j], frames[j + 1]) for j in range(n - 1)]
+    pos = [orc.max_divergence_np(f)[:2] for f in flows]
+    cuts = [bool(orc.mean_mag_np(f) > 7) for f in flows]
+    dots = [float(orc.radial_np(f, c, k)) for f, c, k in zip(flows, orc.smooth_centers(pos), cuts)]
+    want = postchain.actions_from_scalars(dots, cuts, list(range(n - 1)), fps, params)
+    assert got == want and len(got) >= 4
+    out = tmp_path / "clip.funscript"
+    postchain.write_funscript(str(out), got)
+    assert json.load(open(out)) == {"version": "1.0", "actions": want}
+
+
 def test_sharded_engine_single_rank_equals_chunk_engine():
     w, h = 160, 120
     frames = sine_translate_frames(14, w, h, seed=9, amp=(2.5, 1.0), period=7)
