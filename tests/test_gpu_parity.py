@@ -68,6 +68,33 @@ def test_pair_end_to_end(w, h, seed):
             assert ctx.radial([j], [c], [True], False)[0] == 0.0
 
 
+@pytest.mark.parametrize("kind", ["constant", "noise", "checker", "big_shift"])
+def test_degenerate_and_hostile_inputs(kind):
+    """Flat frames (all-zero M, denormal-range sums), uncorrelated noise (large erratic flow, many
+    out-of-bounds warps), a 1-px checkerboard and a 40-px jump (coarse levels dominate)."""
+    w, h = 192, 136
+    rng = np.random.default_rng(42)
+    if kind == "constant":
+        a, b = np.full((h, w), 77, np.uint8), np.full((h, w), 79, np.uint8)
+    elif kind == "noise":
+        a, b = (rng.integers(0, 256, (h, w), dtype=np.uint8) for _ in range(2))
+    elif kind == "checker":
+        y, x = np.mgrid[0:h, 0:w]
+        a = (((x + y) & 1) * 255).astype(np.uint8)
+        b = np.roll(a, 1, axis=1)
+    else:
+        big = sine_translate_frames(1, w + 80, h, seed=6)[0]
+        a, b = np.ascontiguousarray(big[:, 40:40 + w]), np.ascontiguousarray(big[:, :w])
+    with _capi.Context(w, h, max_batch=1) as ctx:
+        ctx.submit_pair(0, a, b)
+        flow = ctx.download_flow(0)
+        x, y, v, mm, cut = ctx.pass1_result(0)
+    ref = orc.farneback(a, b)
+    assert np.array_equal(flow, ref) and np.isfinite(flow).all()
+    ox, oy, ov = orc.max_divergence_np(ref)
+    assert (x, y) == (ox, oy) and np.float32(v).tobytes() == np.float32(ov).tobytes()
+
+
 def test_bgr_upload_matches_gray_path():
     w, h = 320, 180
     fr = frames(2, w, h, seed=5)
