@@ -10,14 +10,15 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libffl_hip.so")
 
 FFL_OK = 0
 FFL_MAX_BATCH = 64
-# kernel classes of ffl_profile_read (index 3 is reserved: the x2 flow upsample is fused into k_update_matrices)
-KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "(reserved)", "k_update_matrices", "k_blur_solve",
+# kernel classes of ffl_profile_read
+KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "k_frontend", "k_update_matrices", "k_blur_solve",
                   "k_pass1", "k_radial"]
 
 # every symbol include/ffl.h declares (tests check that the library exports all of them)
-EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "ffl_upload_frame", "ffl_upload_frames", "ffl_flow_pairs",
+EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "ffl_upload_frame", "ffl_upload_frames", "ffl_upload_frames_raw",
+           "ffl_flow_pairs",
            "ffl_pass1_result", "ffl_pass1_results", "ffl_radial", "ffl_download_flow", "ffl_upload_flow", "ffl_submit_pair", "ffl_sync",
-           "ffl_num_levels", "ffl_level_size", "ffl_debug_pair", "ffl_set_option", "ffl_profile_enable",
+           "ffl_num_levels", "ffl_level_size", "ffl_download_frame", "ffl_debug_pair", "ffl_set_option", "ffl_profile_enable",
            "ffl_profile_read", "ffl_kernel_name"]
 
 
@@ -46,6 +47,8 @@ def load():
     L.ffl_last_error.restype = C.c_char_p
     L.ffl_upload_frame.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t]
     L.ffl_upload_frames.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_ssize_t]
+    L.ffl_upload_frames_raw.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp), C.c_int, C.c_int, C.c_ssize_t, C.c_int,
+                                        C.c_int, C.c_int, C.c_int, C.c_int]
     L.ffl_flow_pairs.argtypes = [vp, C.c_int, ip, ip, ip, C.c_int]
     L.ffl_pass1_result.argtypes = [vp, C.c_int, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                    C.POINTER(C.c_float), C.POINTER(C.c_float), ip]
@@ -53,6 +56,7 @@ def load():
                                     C.POINTER(C.c_float), C.POINTER(C.c_float), ip]
     L.ffl_radial.argtypes = [vp, C.c_int, ip, dp, dp, ip, C.c_int, dp]
     L.ffl_download_flow.argtypes = [vp, C.c_int, vp]
+    L.ffl_download_frame.argtypes = [vp, C.c_int, vp]
     L.ffl_upload_flow.argtypes = [vp, C.c_int, vp, C.c_int]
     L.ffl_submit_pair.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, C.c_ssize_t, C.c_int]
     L.ffl_sync.argtypes = [vp]
@@ -141,6 +145,19 @@ class Context:
         self._chk(self.L.ffl_upload_frames(self._h, first_slot, len(fr), ptrs, f0.shape[1], f0.shape[0], ch,
                                            f0.strides[0]))
 
+    def upload_frames_raw(self, first_slot, frames, resize, crop=(0, 0), rgb_order=False):
+        """Decoded (h, w, 3) uint8 frames -> gray(resize(frame, resize)[crop window]) in consecutive slots
+        (cv2.resize / cv2.cvtColor 8-bit rules on the device; FF:182-186, FF:1076-1082)."""
+        fr = [f if (f.ndim == 3 and f.strides[2] == 1 and f.strides[1] == 3) else np.ascontiguousarray(f) for f in frames]
+        f0 = fr[0]
+        if any(f.dtype != np.uint8 or f.ndim != 3 or f.shape != f0.shape or f.shape[2] != 3 or
+               f.strides[0] != f0.strides[0] for f in fr):
+            raise FFLError("upload_frames_raw needs (h, w, 3) uint8 frames of one shape and row stride")
+        ptrs = (C.c_void_p * len(fr))(*[f.ctypes.data for f in fr])
+        self._chk(self.L.ffl_upload_frames_raw(self._h, first_slot, len(fr), ptrs, f0.shape[1], f0.shape[0],
+                                               f0.strides[0], int(bool(rgb_order)), int(resize[0]), int(resize[1]),
+                                               int(crop[0]), int(crop[1])))
+
     def flow_pairs(self, fslot0, fslot1, flow_slots, pov_mode=False):
         n = len(flow_slots)
         self._chk(self.L.ffl_flow_pairs(self._h, n, _iarr(fslot0), _iarr(fslot1), _iarr(flow_slots), int(bool(pov_mode))))
@@ -173,6 +190,11 @@ class Context:
                                     _darr([c[1] for c in centers]), _iarr([int(bool(c)) for c in is_cut]),
                                     int(bool(pov_mode)), out))
         return [float(v) for v in out]
+
+    def download_frame(self, fslot):
+        out = np.empty((self.height, self.width), np.uint8)
+        self._chk(self.L.ffl_download_frame(self._h, fslot, out.ctypes.data))
+        return out
 
     def download_flow(self, flow_slot):
         out = np.empty((self.height, self.width, 2), np.float32)

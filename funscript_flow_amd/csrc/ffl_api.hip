@@ -20,6 +20,7 @@
 #include <vector>
 
 #define FFL_EV_RING 16
+#define FFL_RAW_RING 4
 
 static thread_local std::string g_create_error = "";
 static int g_num_lanes = 2;  // compute lanes per context created from now on (ffl_set_option "lanes")
@@ -78,6 +79,16 @@ struct ffl_ctx {
     unsigned up_next = 0;
     std::vector<hipEvent_t> ev_last_use;  // [frame slot * n_lanes + lane]: handle of the last batch event, or null
     std::vector<char> frame_valid;
+    // ffl_upload_frames_raw: decoded source frames pass through a small ring of pinned + device buffers
+    // (grown on demand to the largest source seen); `ev` = the frame's k_frontend has consumed the buffer
+    struct RawBuf {
+        uint8_t *h = nullptr, *d = nullptr;
+        size_t cap = 0;
+        hipEvent_t ev = nullptr;
+        bool busy = false;
+    };
+    RawBuf raw[FFL_RAW_RING];
+    unsigned raw_next = 0;
     hipEvent_t post_ring[FFL_EV_RING] = {nullptr};  // events of ffl_upload_flow (s_post)
     unsigned post_next = 0;
     // flow slots
@@ -269,7 +280,7 @@ int ffl_device_count(void) {
 const char *ffl_last_error(const ffl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 const char *ffl_kernel_name(int k) {
-    static const char *names[FFL_K_COUNT] = {"k_gray",  "k_pyr_level", "k_polyexp", "(reserved)",
+    static const char *names[FFL_K_COUNT] = {"k_gray",  "k_pyr_level", "k_polyexp", "k_frontend",
                                              "k_update_matrices", "k_blur_solve", "k_pass1", "k_radial"};
     return (k >= 0 && k < FFL_K_COUNT) ? names[k] : "?";
 }
@@ -287,6 +298,11 @@ void ffl_destroy(ffl_ctx *c) {
     for (auto e : c->post_ring)
         if (e) hipEventDestroy(e);
     hipFree(c->d_gray); hipFree(c->d_bgr); hipHostFree(c->h_stage_gray); hipHostFree(c->h_stage_bgr);
+    for (auto &rb : c->raw) {
+        hipFree(rb.d);
+        hipHostFree(rb.h);
+        if (rb.ev) hipEventDestroy(rb.ev);
+    }
     for (auto &L : c->lanes) {
         hipFree(L.d_I); hipFree(L.d_T); hipFree(L.d_R); hipFree(L.d_M[0]); hipFree(L.d_M[1]);
         hipFree(L.d_flowA); hipFree(L.d_flowB); hipFree(L.d_pkey); hipFree(L.d_psum);
@@ -457,9 +473,90 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
     return FFL_OK;
 }
 
+// Decoded frames -> gray frame slots through k_frontend (resize + crop + luma in one pass).  Frame by
+// frame: tight copy into a pinned ring buffer, H2D, kernel -- the 3 * src_w * src_h byte transfer is the
+// cost, so there is nothing to gain from batching the launches.
+int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *frames, int sw, int sh,
+                          ptrdiff_t stride_bytes, int rgb_order, int rw, int rh, int crop_x, int crop_y) {
+    if (!c) return FFL_ERR_INVALID;
+    if (!frames || n < 1 || first < 0 || first + n > c->n_fslots)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames_raw: bad frame slot range %d..%d", first, first + n - 1);
+    if (sw < 1 || sh < 1 || sw > 32768 || sh > 32768 || rw < 1 || rh < 1 || rw > 32768 || rh > 32768)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames_raw: unsupported source %dx%d / resize %dx%d", sw, sh, rw, rh);
+    if (stride_bytes < (ptrdiff_t)sw * 3)
+        return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames_raw: stride %td < row bytes %d", stride_bytes, sw * 3);
+    if (crop_x < 0 || crop_y < 0 || crop_x + c->w > rw || crop_y + c->h > rh)
+        return set_err(c, FFL_ERR_INVALID,
+                       "ffl_upload_frames_raw: crop window (%d, %d) + %dx%d does not fit the %dx%d resized frame", crop_x,
+                       crop_y, c->w, c->h, rw, rh);
+    for (int i = 0; i < n; i++)
+        if (!frames[i]) return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames_raw: frame %d is NULL", i);
+    HIPCHK(c, hipSetDevice(c->device));
+    FrontParams fp;
+    fp.sw = sw; fp.sh = sh;
+    fp.stride = (size_t)sw * 3;
+    fp.cx = crop_x; fp.cy = crop_y; fp.ow = c->w; fp.oh = c->h;
+    fp.scale_x = 1. / ((double)rw / sw);
+    fp.scale_y = 1. / ((double)rh / sh);
+    fp.mode = (rw == sw && rh == sh) ? FFL_FRONT_IDENTITY
+              : (sw == 2 * rw && sh == 2 * rh) ? FFL_FRONT_AREA2 : FFL_FRONT_GENERIC;
+    fp.rgb = rgb_order != 0;
+    const size_t fbytes = fp.stride * sh;
+    for (int i = 0; i < n; i++) {
+        const int fs = first + i;
+        auto &rb = c->raw[c->raw_next++ % FFL_RAW_RING];
+        if (rb.busy) HIPCHK(c, hipEventSynchronize(rb.ev));  // its previous frame has left both buffers
+        if (rb.cap < fbytes) {
+            hipFree(rb.d);
+            hipHostFree(rb.h);
+            rb.d = rb.h = nullptr;
+            rb.cap = 0;
+            HIPCHK(c, hipMalloc(&rb.d, fbytes));
+            HIPCHK(c, hipHostMalloc(&rb.h, fbytes, hipHostMallocDefault));
+            rb.cap = fbytes;
+        }
+        if (!rb.ev) HIPCHK(c, hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
+        const uint8_t *data = frames[i];
+        if ((size_t)stride_bytes == fp.stride) memcpy(rb.h, data, fbytes);
+        else
+            for (int y = 0; y < sh; y++) memcpy(rb.h + (size_t)y * fp.stride, data + (ptrdiff_t)y * stride_bytes, fp.stride);
+        for (size_t l = 0; l < c->lanes.size(); l++) {  // batches still reading the slot's previous frame
+            hipEvent_t e = c->ev_last_use[(size_t)fs * c->lanes.size() + l];
+            if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
+        }
+        HIPCHK(c, hipMemcpyAsync(rb.d, rb.h, fbytes, hipMemcpyHostToDevice, c->s_copy));
+        {
+            ProfScope ps(c, FFL_K_FRONTEND, c->s_copy);
+            ffl_launch_frontend(rb.d, c->d_gray + (size_t)fs * c->N, fp, c->s_copy);
+        }
+        HIPCHK(c, hipEventRecord(rb.ev, c->s_copy));
+        rb.busy = true;
+    }
+    hipEvent_t ev = c->up_ring[c->up_next++ % (2 * FFL_EV_RING)];
+    HIPCHK(c, hipEventRecord(ev, c->s_copy));
+    for (int i = 0; i < n; i++) {
+        // a gray upload into this slot may still be in flight out of the slot's own staging area; the new
+        // handle is later on the same stream, so waiting on it covers that transfer as well
+        c->ev_uploaded[first + i] = ev;
+        c->frame_valid[first + i] = 1;
+    }
+    return FFL_OK;
+}
+
 int ffl_upload_frame(ffl_ctx *c, int fslot, const uint8_t *data, int width, int height, int channels,
                      ptrdiff_t stride_bytes) {
     return ffl_upload_frames(c, fslot, 1, &data, width, height, channels, stride_bytes);
+}
+
+int ffl_download_frame(ffl_ctx *c, int fslot, uint8_t *dst) {
+    if (!c) return FFL_ERR_INVALID;
+    if (!dst || fslot < 0 || fslot >= c->n_fslots)
+        return set_err(c, FFL_ERR_INVALID, "ffl_download_frame: bad frame slot %d", fslot);
+    if (!c->frame_valid[fslot]) return set_err(c, FFL_ERR_STATE, "ffl_download_frame: frame slot %d was never uploaded", fslot);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipMemcpyAsync(dst, c->d_gray + (size_t)fslot * c->N, c->N, hipMemcpyDeviceToHost, c->s_copy));
+    HIPCHK(c, hipStreamSynchronize(c->s_copy));
+    return FFL_OK;
 }
 
 struct DebugCapture {

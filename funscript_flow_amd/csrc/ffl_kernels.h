@@ -46,7 +46,17 @@ struct Pass1Result {  // written by k_pass1_final, mirrored to pinned host memor
     double mag_sum;   // sum of sqrt(u^2+v^2) over the image (mean = mag_sum / (w*h))
 };
 
+enum { FFL_FRONT_GENERIC = 0, FFL_FRONT_AREA2 = 1, FFL_FRONT_IDENTITY = 2 };
+struct FrontParams {  // k_frontend: decoded 3-channel frame -> gray crop window of its (virtual) resize
+    int sw, sh;              // source size
+    size_t stride;           // source row pitch in bytes (device copy)
+    int cx, cy, ow, oh;      // crop origin inside the resized image, output size
+    double scale_x, scale_y; // 1. / ((double)resize / src), formed on the host
+    int mode, rgb;
+};
+
 // ---- launchers (each enqueues on `st` and returns; no synchronisation) ----------------------
+void ffl_launch_frontend(const uint8_t *src, uint8_t *gray, FrontParams p, hipStream_t st);
 void ffl_launch_gray(const uint8_t *bgr, uint8_t *gray, int n_pixels, hipStream_t st);
 size_t ffl_pyr_tmp_floats(int w, int h, int lw);  // per-frame size of the level's horizontal-pass buffer
 void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, int lw, int lh,

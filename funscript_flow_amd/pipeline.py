@@ -46,8 +46,11 @@ class PairEngine:
     of pairs <= j+6 are known (or the chunk has ended), after which its flow slot is recycled.
     """
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, upload=None):
+        """`upload(first_slot, frames)` puts a run of frames into consecutive frame slots; the default takes
+        gray (or same-size BGR) operands, frontend.DecodedUploader takes frames as decoded (any size)."""
         self.ctx = ctx
+        self.upload = upload or ctx.upload_frames
         self.B = ctx.max_batch
         if ctx.frame_slots < 2 * self.B + 2 or ctx.flow_slots < 3 * self.B + 2 * SMOOTH_RADIUS + 1:
             raise ValueError("context too small: need frame_slots >= 2B+2 and flow_slots >= 3B+13")
@@ -69,7 +72,7 @@ class PairEngine:
                 run = [new[0]]
                 while len(run) < len(new) and new[len(run)] == run[-1] + 1 and fslot(new[len(run)]) == fslot(run[-1]) + 1:
                     run.append(new[len(run)])
-                ctx.upload_frames(fslot(run[0]), [frames[i] for i in run])
+                self.upload(fslot(run[0]), [frames[i] for i in run])
                 for i in run:
                     uploaded[fslot(i)] = i
                 new = new[len(run):]

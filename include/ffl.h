@@ -12,6 +12,9 @@
  *   ffl_upload_frame        the p0/p1 ndarrays handed to precompute_flow_info       FF:843, 1188-1191
  *                           (cuda_GpuMat.upload in the CUDA variant, FF:986-987); also does the
  *                           cv2.cvtColor(..., COLOR_RGB2GRAY) of FF:1082 when given 3 channels
+ *   ffl_upload_frames_raw   the decoded frame's way to that operand: cv2.cvtColor(BGR2RGB) FF:182,
+ *                           cv2.resize(frame, (256, 256)) FF:185-186 (non-VR) or cv2.resize(f, (512, 512))
+ *                           + crop f[256:, :256] FF:1076-1079 (VR), cv2.cvtColor(RGB2GRAY) FF:1079/1082
  *   ffl_flow_pairs          cv2.calcOpticalFlowFarneback(p0,p1,None,0.5,3,15,3,5,1.2,0)  FF:878-879
  *                           + max_divergence(flow)  FF:884 -> FF:748-758
  *                           + cv2.cartToPolar / np.mean                             FF:889-890
@@ -73,6 +76,19 @@ int ffl_upload_frame(ffl_ctx *ctx, int fslot, const uint8_t *data, int width, in
 int ffl_upload_frames(ffl_ctx *ctx, int first_slot, int n, const uint8_t *const *frames, int width, int height,
                       int channels, ptrdiff_t stride_bytes);
 
+/* Input front-end: n decoded 3-channel uint8 frames of src_width x src_height (row pitch
+ * stride_bytes; BGR as cv2.VideoCapture.read returns them, or RGB when rgb_order != 0) go to the frame
+ * slots first_slot .. first_slot+n-1 as
+ *     gray( resize(frame, (resize_width, resize_height)) [crop_y : crop_y+height, crop_x : crop_x+width] )
+ * with width x height the context's frame size, cv2.resize's 8-bit INTER_LINEAR rule (11-bit weights; an
+ * exact 2x2 down-scale takes INTER_AREA's 2x2 mean; equal sizes skip the resize) and cv2's 8-bit luma
+ * (15-bit weights).  The reference's two uses: non-VR (256, 256, 0, 0) on a 256x256 context (FF:185-186,
+ * FF:1082); VR (512, 512, 0, 256) on a 256x256 context (FF:1076-1079).  Only the source pixels the crop
+ * window samples are read on the device.  Pixels are copied to pinned staging before the call returns. */
+int ffl_upload_frames_raw(ffl_ctx *ctx, int first_slot, int n, const uint8_t *const *frames, int src_width,
+                          int src_height, ptrdiff_t stride_bytes, int rgb_order, int resize_width, int resize_height,
+                          int crop_x, int crop_y);
+
 /* Queue Farneback flow + pass-1 reductions for n pairs: pair i = (frame fslot0[i], frame fslot1[i])
  * -> flow slot flow_slots[i].  Frames shared between pairs of the batch are expanded once.
  * pov_mode != 0 skips the divergence argmax (FF:880-882).  Asynchronous. */
@@ -114,6 +130,9 @@ int ffl_num_levels(const ffl_ctx *ctx);
 /* Level-k geometry: out_wh[0]=width, out_wh[1]=height. */
 int ffl_level_size(const ffl_ctx *ctx, int level, int *out_wh);
 
+/* Copy the resident gray frame of `fslot` to host memory (height * width bytes). */
+int ffl_download_frame(ffl_ctx *ctx, int fslot, uint8_t *dst);
+
 /* Run ONE pair (frame slots f0, f1) and capture the level-`level` intermediates as they stand
  * before blur iteration `iter` (0: right after the initial UpdateMatrices; 3: end of level).
  * Any of the output pointers may be NULL.  Planar layouts: R*, M = 5 planes of lh*lw floats;
@@ -138,7 +157,8 @@ int ffl_profile_enable(ffl_ctx *ctx, unsigned class_mask);
 #define FFL_K_GRAY 0
 #define FFL_K_PYRAMID 1
 #define FFL_K_POLYEXP 2
-#define FFL_K_UPSAMPLE 3 /* reserved: the x2 flow upsample runs inside k_update_matrices */
+#define FFL_K_FRONTEND 3 /* k_frontend of ffl_upload_frames_raw (the x2 flow upsample, once class 3, runs
+                            inside k_update_matrices) */
 #define FFL_K_UPDATE_MATRICES 4
 #define FFL_K_BLUR_SOLVE 5
 #define FFL_K_PASS1 6

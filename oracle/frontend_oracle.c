@@ -1,0 +1,119 @@
+/*
+ * oracle/frontend_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * CPU restatement of the reference's per-frame input path, i.e. what
+ * happens to a decoded BGR frame before it becomes one operand of calcOpticalFlowFarneback:
+ *
+ *   cv2.cvtColor(frame, cv2.COLOR_BGR2RGB, frame)              FunscriptFlow.pyw:182
+ *   cv2.resize(frame, (256, 256))            (non-VR)          FunscriptFlow.pyw:185-186, 1057
+ *   cv2.resize(f, (512, 512)); f[256:, :256] (VR)              FunscriptFlow.pyw:1076-1079
+ *   cv2.cvtColor(..., cv2.COLOR_RGB2GRAY)                      FunscriptFlow.pyw:1079, 1082
+ *
+ * PARITY STATUS: **parity unpinned**.  cv2.resize / cv2.cvtColor live in opencv-python 4.11.0.86
+ * (uv.lock:238-239), which is neither in /root/reference nor installed here, and the reference holds
+ * no image fixture.  What follows restates the published 8-bit algorithms of OpenCV 4.x imgproc:
+ *
+ *   resize, INTER_LINEAR, CV_8UC3 (resize.cpp: hal::resize -> resizeGeneric_ with
+ *   HResizeLinear<uchar,int,short,2048> and VResizeLinear<uchar,int,short,FixedPtCast<..., 22>>):
+ *     scale  = 1. / ((double)dst / src)
+ *     fx     = (float)((dx + 0.5) * scale - 0.5);  sx = floor(fx);  fx -= sx
+ *     x only: sx < 0 -> sx = 0, fx = 0;   sx >= src - 1 -> sx = src - 1, fx = 0
+ *     y only: rows sy, sy + 1 clamped to [0, src - 1], fy kept
+ *     alpha  = saturate_cast<short>((1 - fx) * 2048), saturate_cast<short>(fx * 2048)   (round half even)
+ *     H pass : D = S[sx] * alpha0 + S[sx + 1] * alpha1                          (int, per channel)
+ *     V pass : dst = (((beta0 * (D0 >> 4)) >> 16) + ((beta1 * (D1 >> 4)) >> 16) + 2) >> 2
+ *   an exact 2x2 down-scale is re-routed to INTER_AREA's fast path: (s00 + s01 + s10 + s11 + 2) >> 2;
+ *   a same-size "resize" is skipped by the reference itself (FF:185);
+ *
+ *   cvtColor RGB2GRAY, CV_8U (color_rgb.simd.hpp RGB2Gray<uchar>, 15-bit coefficients):
+ *     gray = (R * 9798 + G * 19235 + B * 3735 + 16384) >> 15
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * This file is the two-pass, whole-image form (like OpenCV's); the HIP kernel computes each output
+ * pixel of the crop window directly -- same integers, different organisation.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_API __attribute__((visibility("default")))
+
+static short sat_short_round(float v) {
+    long r = lrintf(v); /* round half to even, like cvRound */
+    if (r > 32767) r = 32767;
+    if (r < -32768) r = -32768;
+    return (short)r;
+}
+
+/* 3-channel u8 bilinear resize; src rows `stride` bytes apart, dst tightly packed (dw*3 per row) */
+ORC_API void orc_resize_linear_u8c3(const uint8_t *src, int sw, int sh, int stride, uint8_t *dst, int dw, int dh) {
+    if (sw == dw && sh == dh) {
+        for (int y = 0; y < sh; y++) memcpy(dst + (size_t)y * dw * 3, src + (size_t)y * stride, (size_t)dw * 3);
+        return;
+    }
+    if (sw == 2 * dw && sh == 2 * dh) { /* INTER_LINEAR -> INTER_AREA fast path */
+        for (int y = 0; y < dh; y++) {
+            const uint8_t *s0 = src + (size_t)(2 * y) * stride, *s1 = s0 + stride;
+            for (int x = 0; x < dw; x++)
+                for (int c = 0; c < 3; c++)
+                    dst[((size_t)y * dw + x) * 3 + c] =
+                        (uint8_t)((s0[6 * x + c] + s0[6 * x + 3 + c] + s1[6 * x + c] + s1[6 * x + 3 + c] + 2) >> 2);
+        }
+        return;
+    }
+    const double scale_x = 1. / ((double)dw / sw), scale_y = 1. / ((double)dh / sh);
+    int *xofs = (int *)malloc(sizeof(int) * dw);
+    short *alpha = (short *)malloc(sizeof(short) * 2 * dw);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = (int)floorf(fx);
+        fx -= sx;
+        if (sx < 0) { sx = 0; fx = 0.f; }
+        if (sx >= sw - 1) { sx = sw - 1; fx = 0.f; }
+        xofs[dx] = sx;
+        alpha[2 * dx] = sat_short_round((1.f - fx) * 2048.f);
+        alpha[2 * dx + 1] = sat_short_round(fx * 2048.f);
+    }
+    int *row0 = (int *)malloc(sizeof(int) * 3 * dw), *row1 = (int *)malloc(sizeof(int) * 3 * dw);
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = (int)floorf(fy);
+        fy -= sy;
+        const short b0 = sat_short_round((1.f - fy) * 2048.f), b1 = sat_short_round(fy * 2048.f);
+        int y0 = sy < 0 ? 0 : (sy > sh - 1 ? sh - 1 : sy);
+        int y1 = sy + 1 < 0 ? 0 : (sy + 1 > sh - 1 ? sh - 1 : sy + 1);
+        const uint8_t *S0 = src + (size_t)y0 * stride, *S1 = src + (size_t)y1 * stride;
+        for (int dx = 0; dx < dw; dx++) {
+            const int sx = xofs[dx], sx1 = sx + 1 < sw ? sx + 1 : sx; /* alpha1 == 0 whenever sx1 is clamped */
+            for (int c = 0; c < 3; c++) {
+                row0[3 * dx + c] = S0[3 * sx + c] * alpha[2 * dx] + S0[3 * sx1 + c] * alpha[2 * dx + 1];
+                row1[3 * dx + c] = S1[3 * sx + c] * alpha[2 * dx] + S1[3 * sx1 + c] * alpha[2 * dx + 1];
+            }
+        }
+        uint8_t *D = dst + (size_t)dy * dw * 3;
+        for (int i = 0; i < 3 * dw; i++)
+            D[i] = (uint8_t)((((b0 * (row0[i] >> 4)) >> 16) + ((b1 * (row1[i] >> 4)) >> 16) + 2) >> 2);
+    }
+    free(xofs); free(alpha); free(row0); free(row1);
+}
+
+/* in-place-capable channel swap: cvtColor(COLOR_BGR2RGB) */
+ORC_API void orc_swap_rb(const uint8_t *src, int w, int h, int stride, uint8_t *dst) {
+    for (int y = 0; y < h; y++)
+        for (int x = 0; x < w; x++) {
+            const uint8_t *s = src + (size_t)y * stride + 3 * x;
+            uint8_t *d = dst + ((size_t)y * w + x) * 3;
+            uint8_t b = s[0], g = s[1], r = s[2];
+            d[0] = r; d[1] = g; d[2] = b;
+        }
+}
+
+/* cvtColor(COLOR_RGB2GRAY) on a (possibly strided) RGB view */
+ORC_API void orc_rgb2gray(const uint8_t *rgb, int w, int h, int stride, uint8_t *gray) {
+    for (int y = 0; y < h; y++) {
+        const uint8_t *s = rgb + (size_t)y * stride;
+        for (int x = 0; x < w; x++)
+            gray[(size_t)y * w + x] = (uint8_t)((s[3 * x] * 9798 + s[3 * x + 1] * 19235 + s[3 * x + 2] * 3735 + 16384) >> 15);
+    }
+}

@@ -27,8 +27,8 @@ _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 
 def build(force=False):
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "farneback_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("farneback_oracle.c", "frontend_oracle.c")]
+    if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -43,6 +43,9 @@ def lib():
         L.orc_gaussian_kernel.argtypes = [C.c_int, C.c_double, _f32p]
         L.orc_bgr2gray.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _u8p]
         L.orc_pyr_level.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]
+        L.orc_resize_linear_u8c3.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
+        L.orc_swap_rb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8p]
+        L.orc_rgb2gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8p]
         L.orc_polyexp_prepare.argtypes = [_f32p, _f32p, _f32p, np.ctypeslib.ndpointer(np.float64)]
         L.orc_polyexp.argtypes = [_f32p, C.c_int, C.c_int, _f32p]
         L.orc_flow_upsample.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int]
@@ -86,6 +89,55 @@ def bgr2gray(bgr):
     out = np.empty((h, w), np.uint8)
     lib().orc_bgr2gray(bgr, w, h, w * 3, out)
     return out
+
+
+def _rows_view(a):
+    """(pointer, row stride) of an (h, w, 3) uint8 array whose pixels are contiguous inside a row"""
+    assert a.dtype == np.uint8 and a.ndim == 3 and a.shape[2] == 3
+    if a.strides[2] != 1 or a.strides[1] != 3 or a.strides[0] < 0:
+        a = np.ascontiguousarray(a)
+    return a, a.strides[0]
+
+
+def swap_rb(img):
+    """cv2.cvtColor(frame, cv2.COLOR_BGR2RGB)   FF:182"""
+    h, w, _ = img.shape
+    out = np.empty((h, w, 3), np.uint8)
+    a, st = _rows_view(img)
+    lib().orc_swap_rb(a.ctypes.data, w, h, st, out)
+    return out
+
+
+def resize_linear_u8c3(img, dw, dh):
+    """cv2.resize(img, (dw, dh)) for an (h, w, 3) uint8 image   FF:186, FF:1076 (parity unpinned)"""
+    h, w, _ = img.shape
+    out = np.empty((dh, dw, 3), np.uint8)
+    a, st = _rows_view(img)
+    lib().orc_resize_linear_u8c3(a.ctypes.data, w, h, st, out, dw, dh)
+    return out
+
+
+def rgb2gray(img):
+    """cv2.cvtColor(img, cv2.COLOR_RGB2GRAY) on an (h, w, 3) view (rows may be strided)   FF:1079, FF:1082"""
+    h, w, _ = img.shape
+    out = np.empty((h, w), np.uint8)
+    a, st = _rows_view(img)
+    lib().orc_rgb2gray(a.ctypes.data, w, h, st, out)
+    return out
+
+
+def frontend(frame_bgr, vr_mode=False, size=(256, 256)):
+    """Decoded BGR frame -> the gray operand of the pair kernel, step by step as the reference does it:
+    BGR2RGB (FF:182); non-VR: resize to `size` unless already that size (FF:185-186, FF:1057) then RGB2GRAY
+    (FF:1082); VR: resize to twice `size`, keep rows [h:], columns [:w] (FF:1076-1079), RGB2GRAY."""
+    w, h = size
+    rgb = swap_rb(frame_bgr)
+    if vr_mode:
+        r = resize_linear_u8c3(rgb, 2 * w, 2 * h)
+        return rgb2gray(r[h:, :w])
+    if rgb.shape[1] != w or rgb.shape[0] != h:
+        rgb = resize_linear_u8c3(rgb, w, h)
+    return rgb2gray(rgb)
 
 
 def pyr_level(img, k):
