@@ -15,6 +15,7 @@ of the per-pair scalars -- no RCCL collective in the data path.
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -76,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
+    ap.add_argument("--trace-steps", action="store_true", help="print per-step host wall times to stderr")
     ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows: 8 or 16")
     ap.add_argument("--lanes", type=int, default=0, help="compute lanes (co-scheduled batches) per context, default 1")
     ap.add_argument("--expand", type=int, default=0, choices=[0, 1, 2],
@@ -131,7 +133,7 @@ def main():
     N = W * H
     U = 2 * B if args.independent else B + 1
     frames = sine_translate_frames(U, W, H, seed=1 if world == 1 else 10 + rank)
-    ctx = _capi.Context(W, H, device=local_rank, frame_slots=U + 1, flow_slots=2 * B, max_batch=B)
+    ctx = _capi.Context(W, H, device=local_rank, frame_slots=U + 1, flow_slots=3 * B, max_batch=B)
     for i in range(U):
         ctx.upload_frame(i, frames[i])
     ctx.sync()
@@ -142,26 +144,37 @@ def main():
 
     results = []
 
+    DEPTH = 2  # batches queued ahead of the one being finalised (flow slots: (DEPTH + 1) * B)
+    jj = np.arange(B)
+    lo, hi = np.maximum(0, jj - SMOOTH_RADIUS), np.minimum(B, jj + SMOOTH_RADIUS + 1)
+
     def enqueue(step):
-        slots = [(step & 1) * B + i for i in range(B)]
+        slots = [(step % (DEPTH + 1)) * B + i for i in range(B)]
         ctx.flow_pairs(f0, f1, slots)
         return slots
 
     def finalize(slots):
-        recs = [ctx.pass1_result(s, 7.0) for s in slots]
-        pos = np.array([[r[0], r[1]] for r in recs], np.float64)
-        cs = [pos[max(0, j - SMOOTH_RADIUS):j + SMOOTH_RADIUS + 1].mean(axis=0) for j in range(B)]
+        recs = ctx.pass1_results(slots, 7.0)                       # one call per batch
+        psum = np.zeros((B + 1, 2), np.int64)                      # FF:1203-1214 inside the batch: exact integer
+        psum[1:] = np.cumsum(np.array([(r[0], r[1]) for r in recs], np.int64), axis=0)   # window sums / counts
+        cs = (psum[hi] - psum[lo]) / (hi - lo)[:, None]
         dots = ctx.radial(slots, cs, [r[4] for r in recs], False)
         results.append((recs, dots))
 
+    TRACE, TRACE2 = [], []
+
     def run(steps):
-        pending = None
+        pending = []
         for s in range(steps):
-            cur = enqueue(s)
-            if pending is not None:
-                finalize(pending)
-            pending = cur
-        finalize(pending)
+            if args.trace_steps:
+                TRACE.append(time.perf_counter())
+            pending.append(enqueue(s))
+            if args.trace_steps:
+                TRACE2.append(time.perf_counter())
+            if len(pending) > DEPTH:
+                finalize(pending.pop(0))
+        while pending:
+            finalize(pending.pop(0))
         ctx.sync()
 
     def barrier():
@@ -174,11 +187,20 @@ def main():
         run(args.warmup)
     results.clear()
     ctx.profile_enable(False if args.no_events else (True if args.profile_all else [DOMINANT]))
+    # A generation-2 collection walks every object torch's import created (40-50 ms: longer than the whole
+    # timed region at small frame sizes); park those objects in the permanent generation first.
+    gc.collect()
+    gc.freeze()
     barrier()
     t0 = time.perf_counter()
     run(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    if TRACE:
+        d = np.diff(np.array(TRACE[-args.steps:])) * 1e3
+        print("step ms:", " ".join(f"{v:.2f}" for v in d), file=sys.stderr)
+        e = (np.array(TRACE2[-args.steps:]) - np.array(TRACE[-args.steps:])) * 1e3
+        print("enqueue ms:", " ".join(f"{v:.2f}" for v in e), file=sys.stderr)
     prof = ctx.profile_read()
     ctx.profile_enable(False)
 

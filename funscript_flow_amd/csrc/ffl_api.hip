@@ -357,8 +357,12 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
         }                                                                                                \
     } while (0)
     CCHK(hipSetDevice(device));
-    CCHK(hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking));
-    CCHK(hipStreamCreateWithFlags(&c->s_post, hipStreamNonBlocking));
+    // uploads and pass 2 are short and latency-critical (the host waits on pass 2): high priority, so
+    // that they get their own hardware queues and are scheduled between a lane's queued kernels
+    int prio_least = 0, prio_greatest = 0;
+    CCHK(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    CCHK(hipStreamCreateWithPriority(&c->s_copy, hipStreamNonBlocking, prio_greatest));
+    CCHK(hipStreamCreateWithPriority(&c->s_post, hipStreamNonBlocking, prio_greatest));
     const size_t N = c->N;
     const int maxU = 2 * max_batch;
     CCHK(hipMalloc(&c->d_gray, (size_t)n_frame_slots * N + 16));  // +16: k_pyr_h fetches taps as aligned words
@@ -369,7 +373,9 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     c->lanes.resize(g_num_lanes);
     for (auto &L : c->lanes) {
         CCHK(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
-        for (auto &s : L.st_aux) CCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        // st_aux (run-ahead / fork-join schedules only) are created on first use: HIP multiplexes streams
+        // onto a few hardware queues, and idle extra streams make the latency-critical `post` / `copy`
+        // streams share a queue with a compute lane (pass 2 then waits behind whole queued batches)
         CCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
         for (auto &e : L.ev_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         size_t r_total = 0, i_total = 0, t_total = 0;
@@ -614,6 +620,8 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     //      the finer levels' expansion (fastest with one lane, but stretches those launches)
     const int mode = cap ? 0 : g_run_ahead;
     if (mode) {
+        for (int k = 0; k < (mode == 2 ? 4 : 1); k++)
+            if (!L.st_aux[k]) HIPCHK(c, hipStreamCreateWithFlags(&L.st_aux[k], hipStreamNonBlocking));
         HIPCHK(c, hipEventRecord(L.ev_fork, st));  // after the uploads and after the lane's previous batch
         for (int k = c->levels; k >= 0; k--) {
             hipStream_t sa = L.st_aux[mode == 2 ? k : 0];

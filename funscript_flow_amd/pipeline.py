@@ -174,10 +174,10 @@ def process_chunk_sharded(engine, frames, rank, world, allgather, pov_mode=False
 class HipShardEngine:
     """engine for process_chunk_sharded on one device: keeps the shard's flows resident."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, upload=None):
         self.ctx = ctx
-        self.inner = PairEngine.__new__(PairEngine)
-        self.inner.ctx, self.inner.B = ctx, ctx.max_batch
+        self.inner = PairEngine.__new__(PairEngine)  # without PairEngine's slot-count check: a shard is bounded below
+        self.inner.ctx, self.inner.B, self.inner.upload = ctx, ctx.max_batch, upload or ctx.upload_frames
 
     def pass1(self, frames, lo, hi, pov_mode, cut_threshold):
         if hi - lo > self.ctx.flow_slots:
