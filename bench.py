@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
     ap.add_argument("--trace-steps", action="store_true", help="print per-step host wall times to stderr")
-    ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows: 8 or 16")
+    ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows (fixed at 16)")
     ap.add_argument("--lanes", type=int, default=0, help="compute lanes (co-scheduled batches) per context, default 1")
     ap.add_argument("--expand", type=int, default=0, choices=[0, 1, 2],
                     help="schedule of the frame-only kernels (pyramid + PolyExp): 0 (default) serial on the lane's "

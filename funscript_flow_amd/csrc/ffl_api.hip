@@ -881,10 +881,8 @@ int ffl_sync(ffl_ctx *c) {
 
 int ffl_set_option(const char *name, int value) {
     if (!name) return FFL_ERR_INVALID;
-    if (!strcmp(name, "blur_tile_h")) {
-        if (value != 8 && value != 16) return FFL_ERR_INVALID;
-        ffl_set_blur_tile_h(value);
-        return FFL_OK;
+    if (!strcmp(name, "blur_tile_h")) {  // fixed: the box-sum order is anchored to blocks of 16 rows
+        return value == 16 ? FFL_OK : FFL_ERR_INVALID;
     }
     if (!strcmp(name, "lanes")) {  // compute lanes of contexts created afterwards
         if (value < 1 || value > 4) return FFL_ERR_INVALID;

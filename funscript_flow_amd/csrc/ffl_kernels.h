@@ -69,7 +69,6 @@ void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, P
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
                            size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st);
 
-void ffl_set_blur_tile_h(int th);  // 8 or 16 (default) rows per k_blur_solve tile (LDS tile sweep)
 
 int ffl_pass1_blocks(int w, int h);
 struct ResTab {  // where each pair's pass-1 record goes

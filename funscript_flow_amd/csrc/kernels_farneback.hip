@@ -484,98 +484,151 @@ void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, P
 
 // ------------------------------------------------------------------------------------------------
 // K5: FarnebackUpdateFlow_Blur: 15x15 box sum of the 5 M planes (double, REPLICATE border, rows
-// then columns, each 15-term sum in the fixed pairwise tree of the oracle's box15()), 2x2 solve in
-// double, flow write, and -- when UPDATE -- the next UpdateMatrices fused on the freshly solved
-// displacement (written to the other M buffer, so neighbouring tiles still read the old M: a Jacobi
-// step, identical to OpenCV's striped in-place update).
+// then columns, every 15-term sum in the position-anchored block order of the oracle's
+// box15_block16()), 2x2 solve in double, flow write, and -- when UPDATE -- the next UpdateMatrices
+// fused on the freshly solved displacement (written to the other M buffer, so neighbouring tiles
+// still read the old M: a Jacobi step, identical to OpenCV's striped in-place update).
 //
-// One 64 x TH output tile per 256-thread workgroup:
-//   phase V  390 lanes = 5 channels x 78 tile columns; each lane reads its TH+14 rows straight from
-//            global memory (consecutive lanes = consecutive x: coalesced), forms the TH column sums
-//            with shared s2/s4/s8 partials (8.6 instead of 14 additions per output) and writes them
-//            to LDS as doubles;
-//   phase H  each lane owns 4 consecutive pixels of one row: 9 ds_read_b128 per channel bring the
-//            18 column sums it needs, the same tree gives the 4 window sums;
+// Summation order (what makes the sums cheap AND bit-identical to the oracle): a column / row is cut
+// into blocks of 16 anchored at 16k-8; the window of position 16k+t is (suffix of block k from t+1,
+// accumulated backwards from the block's end) + (prefix of block k+1 up to t-1, accumulated forwards).
+// The 64x16 tiles are aligned to those blocks, so a lane that owns a whole block column forms its 16
+// sums with 42 additions, and a lane that owns 4 pixels of a block row needs 20.
+//
+// One 64 x 16 output tile per 256-thread workgroup:
+//   phase V  390 lanes = 5 channels x 78 tile columns (two groups, 3 + 2 channels); each lane reads
+//            its 30 rows straight from global memory (consecutive lanes = consecutive x: coalesced),
+//            forms the 16 column sums and writes them to LDS as doubles;
+//   phase H  each lane owns 4 consecutive pixels of one row, wave q of the workgroup the q-th quarter
+//            of every 16-block (so the order of its additions is wave-uniform): 9 ds_read_b128 per
+//            channel bring the 18 column sums it needs;
 //   solve    2x2 system in double, float2 flow store (2 x dwordx4 per lane), fused UpdateMatrices
-//            with dwordx4 R0 loads / M stores.
+//            with 8-byte R0 loads / M stores / R1 gathers.
 // ------------------------------------------------------------------------------------------------
 #ifndef FFL_K5_WAVES
 #define FFL_K5_WAVES 4  // waves per SIMD the register allocator must leave room for (= workgroups per CU)
 #endif
+#ifndef FFL_K5_GROUP
+#define FFL_K5_GROUP 3  // channels that go through LDS together (3 -> 3+2, 2 -> 2+2+1)
+#endif
 
-template <int NOUT, typename T>
-__device__ __forceinline__ void ffl_box15_run(const T (&v)[NOUT + 14], double (&out)[NOUT]) {
-    double s2[NOUT + 12], s4[NOUT + 8], s8[NOUT];
-    double dprev = 0.0;
+// v[0..29] = positions 16k-7 .. 16k+22 of a column (float, widened at use); out[t] = window of 16k+t
+__device__ __forceinline__ void ffl_box_block16(const float (&v)[30], double (&out)[16]) {
+    double s[15];
+    s[14] = (double)v[14];
 #pragma unroll
-    for (int t = 0; t < NOUT + 14; t++) {
-        const double d = (double)v[t];  // widened at first use: only a sliding window of partials is live
-        if (t >= 1 && t - 1 < NOUT + 12) s2[t - 1] = dprev + d;
-        if (t >= 3 && t - 3 < NOUT + 8) s4[t - 3] = s2[t - 3] + s2[t - 1];
-        if (t >= 7 && t - 7 < NOUT) s8[t - 7] = s4[t - 7] + s4[t - 3];
-        if (t >= 14) out[t - 14] = ((s8[t - 14] + s4[t - 6]) + s2[t - 2]) + d;
-        dprev = d;
+    for (int j = 13; j >= 0; j--) s[j] = (double)v[j] + s[j + 1];
+    double p = (double)v[15];
+    out[0] = s[0];
+#pragma unroll
+    for (int t = 1; t < 15; t++) {
+        out[t] = s[t] + p;
+        p = p + (double)v[15 + t];
     }
+    out[15] = p;
 }
 
-template <int TH, bool UPDATE>
+// The same sums for the 4 pixels t = 4Q .. 4Q+3 of a block row: d[0..17] = column sums of positions
+// 16k+4Q-7 .. 16k+4Q+10, of which d[0..NA-1] lie in block k and the rest in block k+1.
+template <int Q>
+__device__ __forceinline__ void ffl_box_quarter(const double (&d)[18], double (&out)[4]) {
+    constexpr int NA = 15 - 4 * Q;
+    double S[4] = {0.0, 0.0, 0.0, 0.0};
+    double s = d[NA - 1];
+    if (NA - 1 < 4) S[NA - 1] = s;
+#pragma unroll
+    for (int j = NA - 2; j >= 0; j--) {
+        s = d[j] + s;
+        if (j < 4) S[j] = s;
+    }
+    double p = d[NA];  // prefix of block k+1 up to offset m: P(m)
+#pragma unroll
+    for (int m = 0; m <= 4 * Q + 2; m++) {
+        if (m > 0) p = p + d[NA + m];
+        const int i = m + 1 - 4 * Q;  // pixel t = 4Q+i takes P(t-1)
+        if (i >= 0 && i < 4) {
+            if (4 * Q + i == 15) out[i] = p;
+            else out[i] = S[i] + p;
+        }
+    }
+    if (Q == 0) out[0] = S[0];  // t = 0: the window is the suffix alone
+}
+
+template <bool UPDATE>
 __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout,
                                                     size_t M_stride, const float *__restrict__ R, size_t R_stride,
                                                     size_t plane, PairTab pt, int w, int h) {
-    constexpr int TW = 64, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
+    constexpr int TW = 64, TH = 16, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
     constexpr int PX = 4;  // consecutive pixels per lane in phase H
-    static_assert(TH == 8 || TH == 16, "one phase-H pass of 256 lanes covers 64 x 16 pixels");
-    // The 5 channels go through LDS in two groups (3 + 2): 3*TH*78 doubles = 30 KB at TH = 16, so
-    // five workgroups fit a CU, and each group's 3*78 / 2*78 column lanes fit one pass of 256 lanes.
-    // double2-typed so that phase H reads with ds_read_b128 (row pitch 624 B = 39 x 16 B).
-    __shared__ double2 sS2[3][TH][LW / 2];
+    // The 5 channels go through LDS in two groups (3 + 2): 3*16*88 doubles = 33 KB, so four workgroups
+    // fit a CU, and each group's 3*78 / 2*78 column lanes fit one pass of 256 lanes.  Column tx of a row
+    // sits at double index tx + 2*(tx >> 4): one 16-byte pad per 16 columns and a row pitch of 44 x 16 B
+    // make the 64 ds_read_b128 of a phase-H wave (16 rows x 4 blocks, 144 B apart) hit 8 distinct
+    // 16-byte bank groups per 8 lanes.
+    constexpr int LW2 = 44;
+    constexpr int GC = FFL_K5_GROUP, NG = (5 + GC - 1) / GC;  // channels per LDS pass, passes
+    __shared__ double2 sS2[GC][TH][LW2];
     const int tid = threadIdx.x;
     int b, tile_x, tile_y;  // XCD-aware panel order, see ffl_tile_coord
     if (!ffl_tile_coord((w + TW - 1) / TW, (h + TH - 1) / TH, b, tile_x, tile_y)) return;
     const int x0 = tile_x * TW, y0 = tile_y * TH;
     const float *Mb = Min + (size_t)b * M_stride;
 
-    const int xg = tid & (TW / PX - 1), ty = tid / (TW / PX);  // phase H: 4 pixels (x0+4xg.., y0+ty)
+    // phase H / solve: wave q owns quarter q of each 16-block; inside the wave 16 rows x 4 blocks
+    const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ty = (tid & 63) >> 2, kk = tid & 3;
+    const int lx0 = 16 * kk + 4 * q;  // first of the lane's 4 pixels (tile coordinates)
     double acc[5][PX];
     double *sS = reinterpret_cast<double *>(&sS2[0][0][0]);
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-        const int c0 = g * 3, nc = g == 0 ? 3 : 2;
+    for (int g = 0; g < NG; g++) {
+        const int c0 = g * GC, nc = min(GC, 5 - c0);
         // ---- phase V: column sums over 15 rows, one (channel, tile column) per lane ------------
         if (g) __syncthreads();  // the previous group's sums have been consumed
         if (tid < nc * LW) {
             const int cc = tid / LW, tx = tid - cc * LW;
             const int gx = min(max(x0 + tx - FFL_WIN_R, 0), w - 1);
-            // wave-uniform row base (scalar registers) + one 32-bit per-lane offset for all 30 loads
-            const unsigned lane_off = (unsigned)((c0 + cc) * plane) + (unsigned)gx;
+            // wave-uniform 64-bit base (a scalar register pair) + a 32-bit per-lane byte offset: the
+            // global_load saddr form -- no per-lane 64-bit address arithmetic, and the row term is one
+            // 32-bit scalar multiply (a pair's 5 M planes are far below 4 GB)
+            const char *Mbb = reinterpret_cast<const char *>(Mb);
+            const unsigned lane_byte = ((unsigned)((c0 + cc) * plane) + (unsigned)gx) * 4u;
+            const unsigned pitch = (unsigned)w * 4u;
             float v[LH];
 #pragma unroll
             for (int j = 0; j < LH; j++) {
-                const int gy = min(max(y0 + j - FFL_WIN_R, 0), h - 1);
-                const float *row = Mb + (size_t)gy * w;
-                v[j] = row[lane_off];
+                const unsigned gy = (unsigned)min(max(y0 + j - FFL_WIN_R, 0), h - 1);
+                v[j] = *reinterpret_cast<const float *>(Mbb + (gy * pitch + lane_byte));
             }
             double o[TH];
-            ffl_box15_run<TH>(v, o);
+            ffl_box_block16(v, o);
+            const int pos = tx + 2 * (tx >> 4);
 #pragma unroll
-            for (int j = 0; j < TH; j++) sS[(cc * TH + j) * LW + tx] = o[j];
+            for (int j = 0; j < TH; j++) sS[(cc * TH + j) * (2 * LW2) + pos] = o[j];
         }
         __syncthreads();
         // ---- phase H: 4 window sums per lane from 18 column sums (9 x ds_read_b128) -------------
-        if (ty < TH) {
 #pragma unroll
-            for (int cc = 0; cc < 3; cc++) {
-                if (cc >= nc) break;
-                double d[PX + 14];
-                const double2 *src = &sS2[cc][ty][xg * (PX / 2)];
-#pragma unroll
-                for (int j = 0; j < (PX + 14) / 2; j++) {
-                    double2 q = src[j];
-                    d[2 * j] = q.x;
-                    d[2 * j + 1] = q.y;
-                }
-                ffl_box15_run<PX>(d, acc[c0 + cc]);
+        for (int cc = 0; cc < GC; cc++) {
+            if (cc >= nc) break;
+            double d[PX + 14];
+            const double2 *src = &sS2[cc][ty][9 * kk];
+#define FFL_K5_H(Q)                                                                        \
+    {                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < (PX + 14) / 2; j++) {                        \
+            const double2 t2 = src[2 * (Q) + j + ((4 * (Q) + 2 * j) >> 4)];                \
+            d[2 * j] = t2.x;                                                               \
+            d[2 * j + 1] = t2.y;                                                           \
+        }                                                                                  \
+        ffl_box_quarter<Q>(d, acc[c0 + cc]);                                               \
+    }
+            switch (q) {
+                case 0: FFL_K5_H(0) break;
+                case 1: FFL_K5_H(1) break;
+                case 2: FFL_K5_H(2) break;
+                default: FFL_K5_H(3) break;
             }
+#undef FFL_K5_H
         }
     }
 
@@ -587,8 +640,11 @@ __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *_
     // the global phase below runs with lanes along x: 512-B flow rows per wave store, and the
     // bilinear gathers of R1 by neighbouring lanes fall into neighbouring addresses.
     __syncthreads();  // every lane has finished reading the column sums
-    float4 *sF4 = reinterpret_cast<float4 *>(&sS2[0][0][0]);  // float2 sF[TH][TW] viewed as float4 pairs
-    if (ty < TH) {
+    // float2 sF[TH][FP] viewed as float4 pairs; row pitch 66 (not 64) float2 so that the 64 32-byte writes
+    // of a wave (16 rows x 4 blocks, all at the same offset inside their 128-byte block) spread over the banks
+    constexpr int FP = TW + 2;
+    float4 *sF4 = reinterpret_cast<float4 *>(&sS2[0][0][0]);
+    {
         float2 f[PX];
 #pragma unroll
         for (int p = 0; p < PX; p++) {
@@ -598,8 +654,8 @@ __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *_
             f[p].x = (float)((g11 * h2 - g12 * h1) * idet);
             f[p].y = (float)((g22 * h1 - g12 * h2) * idet);
         }
-        sF4[(ty * TW + xg * PX) / 2] = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
-        sF4[(ty * TW + xg * PX) / 2 + 1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
+        sF4[(ty * FP + lx0) / 2] = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
+        sF4[(ty * FP + lx0) / 2 + 1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
     }
     __syncthreads();
     // two adjacent pixels per lane: 16-byte flow stores, 8-byte R0 loads / M stores / R1 gathers --
@@ -615,7 +671,7 @@ __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *_
         const int ly = (tid >> 5) + 8 * k;
         const bool in = y0 + ly < h;
         const int y = min(y0 + ly, h - 1);
-        const float4 ff = sF4[(ly * TW + lx) >> 1];
+        const float4 ff = sF4[(ly * FP + lx) >> 1];
         const float2 f0 = make_float2(ff.x, ff.y), f1 = make_float2(ff.z, ff.w);
         const size_t o = (size_t)y * w + x;
         if (in) {
@@ -631,25 +687,13 @@ __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *_
     }
 }
 
-template <int TH>
-static void launch_blur_solve_t(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
-                                size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st) {
-    dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + TH - 1) / TH, nB));
-    if (update)
-        hipLaunchKernelGGL((k_blur_solve<TH, true>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt,
-                           lw, lh);
-    else
-        hipLaunchKernelGGL((k_blur_solve<TH, false>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane,
-                           pt, lw, lh);
-}
-
-static int g_blur_tile_h = 16;
-void ffl_set_blur_tile_h(int th) { g_blur_tile_h = th; }
-
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
                            size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st) {
-    switch (g_blur_tile_h) {
-        case 8: launch_blur_solve_t<8>(Min, Mout, M_stride, R, R_stride, plane, pt, nB, lw, lh, update, st); break;
-        default: launch_blur_solve_t<16>(Min, Mout, M_stride, R, R_stride, plane, pt, nB, lw, lh, update, st); break;
-    }
+    dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + 15) / 16, nB));
+    if (update)
+        hipLaunchKernelGGL((k_blur_solve<true>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
+                           lh);
+    else
+        hipLaunchKernelGGL((k_blur_solve<false>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
+                           lh);
 }

@@ -143,7 +143,9 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 
 /* Process-wide tuning knobs (results never depend on them):
- *   "blur_tile_h" = 8 | 16   rows of the 64-wide k_blur_solve LDS tile (BASELINE configs[2] sweep)
+ *   "blur_tile_h" = 16       rows of the 64-wide k_blur_solve LDS tile.  Fixed since the box-sum order
+ *                            is anchored to blocks of 16 rows / columns (other values are refused); the
+ *                            8 / 16 / 32 sweep of BASELINE configs[2] is recorded in profiles/README.md
  *   "lanes"       = 1..4     compute lanes (co-scheduled batches, each on its own stream and work
  *                            buffers) of contexts created afterwards; default 2
  *   "run_ahead"   = 0|1|2    schedule of the frame-only kernels: 0 serial (default), 1 run-ahead on a

@@ -28,9 +28,9 @@
  *   - float where OpenCV uses float, double where it uses double (PolyExp horizontal
  *     accumulators, box sums, 2x2 solve);
  *   - the 15x15 box sum is the exact-window sum accumulated in double: rows y-7..y+7 first, then
- *     columns x-7..x+7 (REPLICATE border), each 15-term sum in the fixed pairwise tree of box15().
- *     OpenCV reaches the same sums with running (sliding) sums; the two differ only in double
- *     rounding (~1e-16 relative);
+ *     columns x-7..x+7 (REPLICATE border), each 15-term sum in the position-anchored block order
+ *     of box15_block16().  OpenCV reaches the same sums with running (sliding) sums; the two differ
+ *     only in double rounding (~1e-16 relative);
  *   - the separable Gaussian uses the symmetric form k0*c + sum_j kj*(x[-j]+x[+j]) in float,
  *     horizontal pass first, BORDER_REFLECT_101;
  *   - bilinear resize follows OpenCV's coordinate rule for every scale (the exact-2x INTER_AREA
@@ -379,44 +379,61 @@ ORC_API void orc_update_matrices(const float *R0, const float *R1, const float *
 }
 
 /* ---- A.5 FarnebackUpdateFlow_Blur: 15x15 box (double) + 2x2 solve --------------------- */
-/* Sum of the 15 window values v[0..14] in a fixed, position-independent tree:
- *   s2[k] = v[k] + v[k+1],  s4[k] = s2[k] + s2[k+2],  s8[k] = s4[k] + s4[k+4]
- *   window = ((s8[0] + s4[8]) + s2[12]) + v[14]
- * Every partial sum is a pure function of the values it covers, so neighbouring windows share
- * s2/s4/s8 terms bit for bit -- which is what lets the HIP kernel compute 8.6 instead of 14
- * additions per output while staying bit-identical to this loop. */
-static inline double box15(const double *v) {
-    double s2_0 = v[0] + v[1], s2_2 = v[2] + v[3], s2_4 = v[4] + v[5], s2_6 = v[6] + v[7];
-    double s2_8 = v[8] + v[9], s2_10 = v[10] + v[11], s2_12 = v[12] + v[13];
-    double s4_0 = s2_0 + s2_2, s4_4 = s2_4 + s2_6, s4_8 = s2_8 + s2_10;
-    double s8_0 = s4_0 + s4_4;
-    return ((s8_0 + s4_8) + s2_12) + v[14];
+/* The 15-term window sums, in double, in a fixed order that depends only on the window's POSITION (never
+ * on who computes it or on how the image is tiled).  A sequence (a column of M for the vertical pass, a row
+ * of column sums for the horizontal pass) is cut into blocks of 16 anchored at 16k - 8:
+ *     B_k = positions [16k - 8, 16k + 7]
+ * The window of position p = 16k + t (t = 0..15), positions p-7..p+7, touches B_k and B_k+1 only and is
+ *     (the part inside B_k,   accumulated from the END of B_k backwards:   s[j] = v[j] + s[j+1])
+ *   + (the part inside B_k+1, accumulated from the START of B_k+1 forwards: p[j] = p[j-1] + v[j])
+ * (the van Herk / Gil-Werman decomposition; t = 0 is the suffix alone, t = 15 the prefix alone).  All 16
+ * windows of a block share the two running sums: 42 additions per 16 outputs instead of 14 each -- and the
+ * HIP kernel, whose 64x16 tiles are aligned to the same blocks, computes bit-identical sums.  OpenCV itself
+ * uses sliding (add-new, subtract-old) sums; every order differs from the exact sum only by double rounding.
+ * v[0..29] = positions 16k-7 .. 16k+22 (fetched with REPLICATE clamping by the caller); out[t] = window of 16k+t. */
+static void box15_block16(const double *v, double *out) {
+    double s[15];
+    s[14] = v[14];
+    for (int j = 13; j >= 0; j--) s[j] = v[j] + s[j + 1];
+    double p = v[15];
+    out[0] = s[0];
+    for (int t = 1; t < 15; t++) {
+        out[t] = s[t] + p;
+        p = p + v[15 + t];
+    }
+    out[15] = p;
 }
 
 ORC_API void orc_blur_solve(const float *M, int w, int h, float *flow) {
-    const int m = WINSIZE / 2;
     const double scale = 1. / (WINSIZE * WINSIZE);
     size_t pl = (size_t)w * h;
-    double *vs = (double *)malloc(sizeof(double) * 5 * (size_t)w);
-    for (int y = 0; y < h; y++) {
+    double *vs = (double *)malloc(sizeof(double) * 16 * 5 * (size_t)w); /* column sums of one block of 16 rows */
+    for (int yb = 0; yb < h; yb += 16) {
         for (int c = 0; c < 5; c++)
             for (int x = 0; x < w; x++) {
-                double v[WINSIZE];
-                for (int j = -m; j <= m; j++) v[j + m] = (double)M[c * pl + (size_t)clampi(y + j, 0, h - 1) * w + x];
-                vs[c * (size_t)w + x] = box15(v);
+                double v[30], o[16];
+                for (int j = 0; j < 30; j++) v[j] = (double)M[c * pl + (size_t)clampi(yb - 7 + j, 0, h - 1) * w + x];
+                box15_block16(v, o);
+                for (int t = 0; t < 16; t++) vs[((size_t)t * 5 + c) * w + x] = o[t];
             }
-        for (int x = 0; x < w; x++) {
-            double b[5];
-            for (int c = 0; c < 5; c++) {
-                double v[WINSIZE];
-                for (int i = -m; i <= m; i++) v[i + m] = vs[c * (size_t)w + clampi(x + i, 0, w - 1)];
-                b[c] = box15(v);
+        for (int t = 0; t < 16 && yb + t < h; t++) {
+            const int y = yb + t;
+            for (int xb = 0; xb < w; xb += 16) {
+                double b[5][16];
+                for (int c = 0; c < 5; c++) {
+                    double v[30];
+                    for (int i = 0; i < 30; i++) v[i] = vs[((size_t)t * 5 + c) * w + clampi(xb - 7 + i, 0, w - 1)];
+                    box15_block16(v, b[c]);
+                }
+                for (int i = 0; i < 16 && xb + i < w; i++) {
+                    const int x = xb + i;
+                    double g11 = b[0][i] * scale, g12 = b[1][i] * scale, g22 = b[2][i] * scale, h1 = b[3][i] * scale,
+                           h2 = b[4][i] * scale;
+                    double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+                    flow[((size_t)y * w + x) * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+                    flow[((size_t)y * w + x) * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+                }
             }
-            double g11 = b[0] * scale, g12 = b[1] * scale, g22 = b[2] * scale, h1 = b[3] * scale,
-                   h2 = b[4] * scale;
-            double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
-            flow[((size_t)y * w + x) * 2] = (float)((g11 * h2 - g12 * h1) * idet);
-            flow[((size_t)y * w + x) * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
         }
     }
     free(vs);

@@ -156,14 +156,13 @@ def test_results_do_not_depend_on_batching_or_slots():
 
 
 def test_results_do_not_depend_on_schedule_options():
-    """Compute lanes (co-scheduled batches), the frame-expansion schedules and the LDS tile height are
-    speed knobs only: many small batches in flight on recycled frame/flow slots give identical bits."""
+    """Compute lanes (co-scheduled batches) and the frame-expansion schedules are speed knobs only: many small batches in flight on recycled frame/flow slots give identical bits."""
     w, h = 192, 144
     n = 21
     fr = sine_translate_frames(n + 1, w, h, seed=33, amp=(2.0, 1.0), period=9)
     want = None
     try:
-        for lanes, run_ahead, tile in [(1, 0, 16), (2, 0, 16), (2, 1, 8), (3, 2, 16), (1, 1, 16)]:
+        for lanes, run_ahead, tile in [(1, 0, 16), (2, 0, 16), (2, 1, 16), (3, 2, 16), (1, 1, 16)]:
             _capi.set_option("lanes", lanes)
             _capi.set_option("run_ahead", run_ahead)
             _capi.set_option("blur_tile_h", tile)

@@ -145,3 +145,22 @@ def test_bgr2gray_fixed_point():
     b, gg, r = (bgr[..., i].astype(np.int64) for i in range(3))
     assert np.array_equal(g, ((b * 3735 + gg * 19235 + r * 9798 + 16384) >> 15).astype(np.uint8))
     assert np.array_equal(orc.bgr2gray(np.full((4, 4, 3), 255, np.uint8)), np.full((4, 4), 255, np.uint8))
+
+
+@pytest.mark.parametrize("w,h", [(40, 33), (16, 16), (97, 50), (15, 70)])
+def test_blur_solve_against_exact_window_sums(w, h):
+    """FarnebackUpdateFlow_Blur: the oracle's position-anchored summation order (blocks of 16, suffix +
+    prefix) is only an ORDER -- every 15x15 REPLICATE-border window sum must equal the plain numpy sum to
+    double rounding, for sizes that are / are not multiples of the block and smaller than one block."""
+    rng = np.random.default_rng(w * 100 + h)
+    M = (rng.standard_normal((5, h, w)) * np.array([4, 1, 4, 2, 2])[:, None, None]).astype(np.float32)
+    M[0] = np.abs(M[0]) + 1
+    M[2] = np.abs(M[2]) + 1
+    P = np.pad(M.astype(np.float64), ((0, 0), (7, 7), (7, 7)), mode="edge")
+    col = sum(P[:, j:j + h, :] for j in range(15))
+    box = sum(col[:, :, i:i + w] for i in range(15)) / 225.0
+    g11, g12, g22, h1, h2 = box
+    idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3)
+    want = np.stack([(g11 * h2 - g12 * h1) * idet, (g22 * h1 - g12 * h2) * idet], -1)
+    got = orc.blur_solve(M)
+    assert np.allclose(got, want, rtol=2e-6, atol=1e-7)
