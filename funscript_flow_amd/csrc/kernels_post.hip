@@ -7,13 +7,19 @@
 #include "ffl_kernels.h"
 
 #define P1_THREADS 256
+#define P1_RG 16          // rows a wave walks down (its row group)
+#define P1_STRIP 126      // useful pixels of a pass-1 strip: 64 lanes x 2 pixels minus one halo pixel per side
+#define P2_STRIP 128      // pass 2 needs no halo
 
-int ffl_pass1_blocks(int w, int h) {
-    long n = (long)w * h;
-    long blocks = (n + P1_THREADS * 8 - 1) / (P1_THREADS * 8);
-    if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
-    return (int)blocks;
+// Both passes walk the flow field in column strips: a wave owns 128 consecutive pixels of a row (two per
+// lane, one 16-byte load) and walks down P1_RG rows, so every pixel is read once with full-width loads,
+// the vertical neighbours of pass 1 are the previous / next row already in registers and the horizontal
+// ones come from the adjacent lanes.  No per-pixel index division, no neighbour gathers.
+static inline int ffl_strip_waves(int w, int h, int strip) {
+    return ((w + strip - 1) / strip) * ((h + P1_RG - 1) / P1_RG);
+}
+int ffl_pass1_blocks(int w, int h) {  // workgroups (= partial results) per pair, the larger of the two passes
+    return (ffl_strip_waves(w, h, P1_STRIP) + 3) / 4;
 }
 
 // np.gradient along one axis: central difference /2 inside, one-sided at the ends (FF:754)
@@ -27,6 +33,17 @@ __device__ __forceinline__ float ffl_div_at(const float2 *__restrict__ flow, int
     float du = ffl_grad(flow[(size_t)ya * w + x].x, flow[(size_t)yb * w + x].x, y, h);   // d(u)/dy
     float dv = ffl_grad(flow[(size_t)y * w + xa].y, flow[(size_t)y * w + xb].y, x, w);   // d(v)/dx
     return du + dv;
+}
+
+// the lane's two pixels (x, x+1) of row y, each clamped into the image, with one 16-byte load
+__device__ __forceinline__ void ffl_load_pair(const float2 *__restrict__ flow, int w, int h, int x, int y, float2 &p0,
+                                              float2 &p1) {
+    const int yc = min(max(y, 0), h - 1);
+    const int xa = min(max(x, 0), w - 2);  // pair start inside the row
+    const ffl_f4u t = *reinterpret_cast<const ffl_f4u *>(flow + (size_t)yc * w + xa);
+    const float2 A = make_float2(t.x, t.y), B = make_float2(t.z, t.w);
+    p0 = (min(max(x, 0), w - 1) == xa) ? A : B;
+    p1 = (min(max(x + 1, 0), w - 1) == xa) ? A : B;
 }
 
 __device__ __forceinline__ unsigned long long ffl_wave_max_u64(unsigned long long v) {
@@ -53,25 +70,47 @@ __global__ __launch_bounds__(P1_THREADS) void k_pass1(PairTab pt, int w, int h, 
     __shared__ double ssum[P1_THREADS / 64];
     const int b = blockIdx.y;
     const float2 *flow = reinterpret_cast<const float2 *>(pt.flow[b]);
-    const unsigned n = (unsigned)w * (unsigned)h;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nstrips = (w + P1_STRIP - 1) / P1_STRIP, ngroups = (h + P1_RG - 1) / P1_RG;
+    const int wid = blockIdx.x * (P1_THREADS / 64) + wv;  // wave-uniform
     unsigned long long key = 0;
     double sum = 0.0;
-    // unrolled x4 (same element order per lane): the loads of 4 grid-stride steps are in flight
-    // together instead of one memory latency per step
-#pragma unroll 4
-    for (unsigned i = blockIdx.x * P1_THREADS + threadIdx.x; i < n; i += gridDim.x * P1_THREADS) {
-        int y = i / w, x = i - y * w;
-        float2 f = flow[i];
-        sum += (double)sqrtf(f.x * f.x + f.y * f.y);
-        if (!pov_mode) {
-            float d = fabsf(ffl_div_at(flow, w, h, x, y));
-            unsigned long long k = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned long long)(0xFFFFFFFFu - i);
-            key = k > key ? k : key;
+    if (wid < nstrips * ngroups) {
+        const int grp = wid / nstrips, strip = wid - grp * nstrips;
+        const int x = strip * P1_STRIP - 1 + 2 * lane, y0 = grp * P1_RG;  // the lane's pixels: x, x+1
+        // a pixel counts if it is inside the image and not one of the strip's two halo pixels
+        const bool ok0 = lane > 0 && x < w, ok1 = lane < 63 && x + 1 < w;
+        float2 up0, up1, c0, c1, dn0, dn1;
+        ffl_load_pair(flow, w, h, x, y0 - 1, up0, up1);
+        ffl_load_pair(flow, w, h, x, y0, c0, c1);
+#pragma unroll
+        for (int r = 0; r < P1_RG; r++) {
+            const int y = y0 + r;
+            ffl_load_pair(flow, w, h, x, y + 1, dn0, dn1);  // clamped: rows past the end repeat row h-1
+            const bool row_ok = y < h;
+            sum += (ok0 && row_ok) ? (double)sqrtf(c0.x * c0.x + c0.y * c0.y) : 0.0;
+            sum += (ok1 && row_ok) ? (double)sqrtf(c1.x * c1.x + c1.y * c1.y) : 0.0;
+            if (!pov_mode) {
+                // horizontal neighbours: the adjacent lanes' pixels (clamped loads make x = 0 / w-1 see themselves)
+                const float left0 = __shfl_up(c1.y, 1, 64), right1 = __shfl_down(c0.y, 1, 64);
+                const float d0 = fabsf(ffl_grad(up0.x, dn0.x, y, h) + ffl_grad(left0, c1.y, x, w));
+                const float d1 = fabsf(ffl_grad(up1.x, dn1.x, y, h) + ffl_grad(c0.y, right1, x + 1, w));
+                const unsigned i0 = (unsigned)y * (unsigned)w + (unsigned)x;
+                if (ok0 && row_ok) {
+                    const unsigned long long k = ((unsigned long long)__float_as_uint(d0) << 32) | (unsigned long long)(0xFFFFFFFFu - i0);
+                    key = k > key ? k : key;
+                }
+                if (ok1 && row_ok) {
+                    const unsigned long long k = ((unsigned long long)__float_as_uint(d1) << 32) | (unsigned long long)(0xFFFFFFFFu - (i0 + 1u));
+                    key = k > key ? k : key;
+                }
+            }
+            up0 = c0; up1 = c1;
+            c0 = dn0; c1 = dn1;
         }
     }
     key = ffl_wave_max_u64(key);
     sum = ffl_wave_sum_f64(sum);
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { skey[wv] = key; ssum[wv] = sum; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -127,7 +166,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_pass1_final(PairTab pt, int w, i
 
 void ffl_launch_pass1(PairTab pt, int nB, int w, int h, int pov_mode, unsigned long long *pkey, double *psum,
                       ResTab results, hipStream_t st) {
-    int nblk = ffl_pass1_blocks(w, h);
+    int nblk = (ffl_strip_waves(w, h, P1_STRIP) + 3) / 4;
     hipLaunchKernelGGL(k_pass1, dim3(nblk, nB), dim3(P1_THREADS), 0, st, pt, w, h, pov_mode, pkey, psum);
     hipLaunchKernelGGL(k_pass1_final, dim3(nB), dim3(P1_THREADS), 0, st, pt, w, h, pov_mode, nblk, pkey, psum, results);
 }
@@ -140,22 +179,32 @@ __global__ __launch_bounds__(P1_THREADS) void k_radial(RadialTab rt, int w, int 
     const float2 *flow = reinterpret_cast<const float2 *>(rt.flow[b]);
     const double cx = rt.cx[b], cy = rt.cy[b];
     const double dw = (double)w, dh = (double)h;
-    const unsigned n = (unsigned)w * (unsigned)h;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int nstrips = (w + P2_STRIP - 1) / P2_STRIP, ngroups = (h + P1_RG - 1) / P1_RG;
+    const int wid = blockIdx.x * (P1_THREADS / 64) + wv;  // wave-uniform
     double sum = 0.0;
-#pragma unroll 4
-    for (unsigned i = blockIdx.x * P1_THREADS + threadIdx.x; i < n; i += gridDim.x * P1_THREADS) {
-        int y = i / w, x = i - y * w;
-        float2 f = flow[i];
-        double dx = (double)x - cx, dy = (double)y - cy;
-        double dot = (double)f.x * dx + (double)f.y * dy;
-        if (!pov_mode) {
-            dot = ((double)x > cx) ? dot * (double)(w - x) / dw : dot * (double)x / dw;
-            dot = ((double)y > cy) ? dot * (double)(h - y) / dh : dot * (double)y / dh;
+    if (wid < nstrips * ngroups) {
+        const int grp = wid / nstrips, strip = wid - grp * nstrips;
+        const int x = strip * P2_STRIP + 2 * lane, y0 = grp * P1_RG;  // the lane's pixels: x, x+1
+        const bool ok0 = x < w, ok1 = x + 1 < w;
+        // per-column terms once per lane: dx and the quadrant weight (w - x) / w or x / w  (FF:776-779)
+        const double dx0 = (double)x - cx, dx1 = (double)(x + 1) - cx;
+        const double wx0 = pov_mode ? 1.0 : (((double)x > cx) ? (double)(w - x) / dw : (double)x / dw);
+        const double wx1 = pov_mode ? 1.0 : (((double)(x + 1) > cx) ? (double)(w - x - 1) / dw : (double)(x + 1) / dw);
+#pragma unroll
+        for (int r = 0; r < P1_RG; r++) {
+            const int y = y0 + r;
+            float2 f0, f1;
+            ffl_load_pair(flow, w, h, x, y, f0, f1);
+            const double dy = (double)y - cy;
+            const double wy = pov_mode ? 1.0 : (((double)y > cy) ? (double)(h - y) / dh : (double)y / dh);
+            const double t0 = ((double)f0.x * dx0 + (double)f0.y * dy) * wx0 * wy;
+            const double t1 = ((double)f1.x * dx1 + (double)f1.y * dy) * wx1 * wy;
+            sum += (ok0 && y < h) ? t0 : 0.0;
+            sum += (ok1 && y < h) ? t1 : 0.0;
         }
-        sum += dot;
     }
     sum = ffl_wave_sum_f64(sum);
-    int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) ssum[wv] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -181,7 +230,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_radial_final(int w, int h, int n
 }
 
 void ffl_launch_radial(RadialTab rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st) {
-    int nblk = ffl_pass1_blocks(w, h);
+    int nblk = (ffl_strip_waves(w, h, P2_STRIP) + 3) / 4;
     hipLaunchKernelGGL(k_radial, dim3(nblk, nB), dim3(P1_THREADS), 0, st, rt, w, h, pov_mode, psum);
     hipLaunchKernelGGL(k_radial_final, dim3(nB), dim3(P1_THREADS), 0, st, w, h, nblk, psum, out);
 }
