@@ -77,6 +77,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
+    ap.add_argument("--blur-rows", type=int, default=0, help="tiles a k_blur_solve workgroup walks down (0 = automatic)")
     ap.add_argument("--trace-steps", action="store_true", help="print per-step host wall times to stderr")
     ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows (fixed at 16)")
     ap.add_argument("--lanes", type=int, default=0, help="compute lanes (co-scheduled batches) per context, default 1")
@@ -121,6 +122,8 @@ def main():
     from funscript_flow_amd.pipeline import SMOOTH_RADIUS
     from funscript_flow_amd.synth import sine_translate_frames
 
+    if args.blur_rows:
+        _capi.set_option("blur_rows", args.blur_rows)
     if args.blur_tile_h:
         _capi.set_option("blur_tile_h", args.blur_tile_h)
     # One compute lane by default: kernels of consecutive batches then run back to back, so the

@@ -884,6 +884,11 @@ int ffl_set_option(const char *name, int value) {
     if (!strcmp(name, "blur_tile_h")) {  // fixed: the box-sum order is anchored to blocks of 16 rows
         return value == 16 ? FFL_OK : FFL_ERR_INVALID;
     }
+    if (!strcmp(name, "blur_rows")) {  // tiles a k_blur_solve workgroup walks down: 0 automatic, 1..64
+        if (value < 0 || value > 64) return FFL_ERR_INVALID;
+        ffl_set_blur_rows(value);
+        return FFL_OK;
+    }
     if (!strcmp(name, "lanes")) {  // compute lanes of contexts created afterwards
         if (value < 1 || value > 4) return FFL_ERR_INVALID;
         g_num_lanes = value;

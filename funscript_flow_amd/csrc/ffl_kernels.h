@@ -70,6 +70,8 @@ void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const
                            size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st);
 
 
+void ffl_set_blur_rows(int n);  // tiles a k_blur_solve workgroup walks down (0 = automatic)
+
 int ffl_pass1_blocks(int w, int h);
 struct ResTab {  // where each pair's pass-1 record goes
     Pass1Result *r[FFL_MAXB];

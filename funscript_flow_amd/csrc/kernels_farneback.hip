@@ -554,12 +554,16 @@ __device__ __forceinline__ void ffl_box_quarter(const double (&d)[18], double (&
     if (Q == 0) out[0] = S[0];  // t = 0: the window is the suffix alone
 }
 
+static int g_blur_rows = 0;  // 0: automatic (ffl_blur_rows_per_wg)
+void ffl_set_blur_rows(int n) { g_blur_rows = n; }
+
 template <bool UPDATE>
 __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout,
                                                     size_t M_stride, const float *__restrict__ R, size_t R_stride,
-                                                    size_t plane, PairTab pt, int w, int h) {
+                                                    size_t plane, PairTab pt, int w, int h, int nrb) {
     constexpr int TW = 64, TH = 16, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
     constexpr int PX = 4;  // consecutive pixels per lane in phase H
+    constexpr int NCARRY = LH - TH;  // rows of a tile's 30 that the tile below needs again
     // The 5 channels go through LDS in two groups (3 + 2): 3*16*88 doubles = 33 KB, so four workgroups
     // fit a CU, and each group's 3*78 / 2*78 column lanes fit one pass of 256 lanes.  Column tx of a row
     // sits at double index tx + 2*(tx >> 4): one 16-byte pad per 16 columns and a row pitch of 44 x 16 B
@@ -569,50 +573,81 @@ __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *_
     constexpr int GC = FFL_K5_GROUP, NG = (5 + GC - 1) / GC;  // channels per LDS pass, passes
     __shared__ double2 sS2[GC][TH][LW2];
     const int tid = threadIdx.x;
-    int b, tile_x, tile_y;  // XCD-aware panel order, see ffl_tile_coord
-    if (!ffl_tile_coord((w + TW - 1) / TW, (h + TH - 1) / TH, b, tile_x, tile_y)) return;
-    const int x0 = tile_x * TW, y0 = tile_y * TH;
+    // A workgroup walks down `nrb` vertically adjacent tiles (a column strip of 64 x 16*nrb pixels) and
+    // keeps the 14 rows two consecutive tiles share in registers: phase V then loads 16 new rows per tile
+    // instead of 30 -- its halo re-reads (30 rows for 16 outputs) were the kernel's largest single cost.
+    int b, tile_x, strip_y;  // XCD-aware panel order over the strips, see ffl_tile_coord
+    const int tiles_y = (h + TH - 1) / TH;
+    if (!ffl_tile_coord((w + TW - 1) / TW, (tiles_y + nrb - 1) / nrb, b, tile_x, strip_y)) return;
+    const int x0 = tile_x * TW;
     const float *Mb = Min + (size_t)b * M_stride;
 
     // phase H / solve: wave q owns quarter q of each 16-block; inside the wave 16 rows x 4 blocks
     const int q = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ty = (tid & 63) >> 2, kk = tid & 3;
     const int lx0 = 16 * kk + 4 * q;  // first of the lane's 4 pixels (tile coordinates)
-    double acc[5][PX];
     double *sS = reinterpret_cast<double *>(&sS2[0][0][0]);
+    // phase V: (channel of the group, tile column) of this lane; the same for both groups
+    const int vcc = tid / LW, vtx = tid - vcc * LW;
+    const int vgx = min(max(x0 + vtx - FFL_WIN_R, 0), w - 1);
+    const unsigned pitch = (unsigned)w * 4u;
+    float carry[NG][NCARRY];
+    const double scale = 1.0 / (FFL_WIN * FFL_WIN);
+    float2 *flow = reinterpret_cast<float2 *>(pt.flow[b]);
+    const float *R0 = R + (size_t)pt.u0[b] * R_stride, *R1 = R + (size_t)pt.u1[b] * R_stride;
+    float *Mo = Mout + (size_t)b * M_stride;
+    // float2 sF[TH][FP] viewed as float4 pairs; row pitch 66 (not 64) float2 so that the 64 32-byte writes
+    // of a wave (16 rows x 4 blocks, all at the same offset inside their 128-byte block) spread over the banks
+    constexpr int FP = TW + 2;
+    float4 *sF4 = reinterpret_cast<float4 *>(&sS2[0][0][0]);
+
+#pragma unroll 1
+    for (int rb = 0; rb < nrb; rb++) {
+        const int y0 = (strip_y * nrb + rb) * TH;
+        if (y0 >= h) break;
+        double acc[5][PX];
 #pragma unroll
-    for (int g = 0; g < NG; g++) {
-        const int c0 = g * GC, nc = min(GC, 5 - c0);
-        // ---- phase V: column sums over 15 rows, one (channel, tile column) per lane ------------
-        if (g) __syncthreads();  // the previous group's sums have been consumed
-        if (tid < nc * LW) {
-            const int cc = tid / LW, tx = tid - cc * LW;
-            const int gx = min(max(x0 + tx - FFL_WIN_R, 0), w - 1);
-            // wave-uniform 64-bit base (a scalar register pair) + a 32-bit per-lane byte offset: the
-            // global_load saddr form -- no per-lane 64-bit address arithmetic, and the row term is one
-            // 32-bit scalar multiply (a pair's 5 M planes are far below 4 GB)
-            const char *Mbb = reinterpret_cast<const char *>(Mb);
-            const unsigned lane_byte = ((unsigned)((c0 + cc) * plane) + (unsigned)gx) * 4u;
-            const unsigned pitch = (unsigned)w * 4u;
-            float v[LH];
+        for (int g = 0; g < NG; g++) {
+            const int c0 = g * GC, nc = min(GC, 5 - c0);
+            // ---- phase V: column sums over 15 rows, one (channel, tile column) per lane ------------
+            if (g) __syncthreads();  // the previous group's sums have been consumed
+            if (tid < nc * LW) {
+                // wave-uniform 64-bit base (a scalar register pair) + a 32-bit per-lane byte offset: the
+                // global_load saddr form -- no per-lane 64-bit address arithmetic, and the row term is one
+                // 32-bit scalar multiply (a pair's 5 M planes are far below 4 GB)
+                const char *Mbb = reinterpret_cast<const char *>(Mb);
+                const unsigned lane_byte = ((unsigned)((c0 + vcc) * plane) + (unsigned)vgx) * 4u;
+                float v[LH];
+                if (rb == 0) {
 #pragma unroll
-            for (int j = 0; j < LH; j++) {
-                const unsigned gy = (unsigned)min(max(y0 + j - FFL_WIN_R, 0), h - 1);
-                v[j] = *reinterpret_cast<const float *>(Mbb + (gy * pitch + lane_byte));
+                    for (int j = 0; j < NCARRY; j++) {
+                        const unsigned gy = (unsigned)min(max(y0 + j - FFL_WIN_R, 0), h - 1);
+                        v[j] = *reinterpret_cast<const float *>(Mbb + (gy * pitch + lane_byte));
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NCARRY; j++) v[j] = carry[g][j];
+                }
+#pragma unroll
+                for (int j = NCARRY; j < LH; j++) {
+                    const unsigned gy = (unsigned)min(max(y0 + j - FFL_WIN_R, 0), h - 1);
+                    v[j] = *reinterpret_cast<const float *>(Mbb + (gy * pitch + lane_byte));
+                }
+#pragma unroll
+                for (int j = 0; j < NCARRY; j++) carry[g][j] = v[TH + j];
+                double o[TH];
+                ffl_box_block16(v, o);
+                const int pos = vtx + 2 * (vtx >> 4);
+#pragma unroll
+                for (int j = 0; j < TH; j++) sS[(vcc * TH + j) * (2 * LW2) + pos] = o[j];
             }
-            double o[TH];
-            ffl_box_block16(v, o);
-            const int pos = tx + 2 * (tx >> 4);
+            __syncthreads();
+            // ---- phase H: 4 window sums per lane from 18 column sums (9 x ds_read_b128) -------------
 #pragma unroll
-            for (int j = 0; j < TH; j++) sS[(cc * TH + j) * (2 * LW2) + pos] = o[j];
-        }
-        __syncthreads();
-        // ---- phase H: 4 window sums per lane from 18 column sums (9 x ds_read_b128) -------------
-#pragma unroll
-        for (int cc = 0; cc < GC; cc++) {
-            if (cc >= nc) break;
-            double d[PX + 14];
-            const double2 *src = &sS2[cc][ty][9 * kk];
+            for (int cc = 0; cc < GC; cc++) {
+                if (cc >= nc) break;
+                double d[PX + 14];
+                const double2 *src = &sS2[cc][ty][9 * kk];
 #define FFL_K5_H(Q)                                                                        \
     {                                                                                      \
         _Pragma("unroll") for (int j = 0; j < (PX + 14) / 2; j++) {                        \
@@ -622,78 +657,84 @@ __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *_
         }                                                                                  \
         ffl_box_quarter<Q>(d, acc[c0 + cc]);                                               \
     }
-            switch (q) {
-                case 0: FFL_K5_H(0) break;
-                case 1: FFL_K5_H(1) break;
-                case 2: FFL_K5_H(2) break;
-                default: FFL_K5_H(3) break;
-            }
+                switch (q) {
+                    case 0: FFL_K5_H(0) break;
+                    case 1: FFL_K5_H(1) break;
+                    case 2: FFL_K5_H(2) break;
+                    default: FFL_K5_H(3) break;
+                }
 #undef FFL_K5_H
-        }
-    }
-
-    // ---- solve (+ fused UpdateMatrices) ---------------------------------------------------------------
-    const double scale = 1.0 / (FFL_WIN * FFL_WIN);
-    float2 *flow = reinterpret_cast<float2 *>(pt.flow[b]);
-    const float *R0 = R + (size_t)pt.u0[b] * R_stride, *R1 = R + (size_t)pt.u1[b] * R_stride;
-    // The solved displacements are transposed through LDS (aliasing the column-sum buffer) so that
-    // the global phase below runs with lanes along x: 512-B flow rows per wave store, and the
-    // bilinear gathers of R1 by neighbouring lanes fall into neighbouring addresses.
-    __syncthreads();  // every lane has finished reading the column sums
-    // float2 sF[TH][FP] viewed as float4 pairs; row pitch 66 (not 64) float2 so that the 64 32-byte writes
-    // of a wave (16 rows x 4 blocks, all at the same offset inside their 128-byte block) spread over the banks
-    constexpr int FP = TW + 2;
-    float4 *sF4 = reinterpret_cast<float4 *>(&sS2[0][0][0]);
-    {
-        float2 f[PX];
-#pragma unroll
-        for (int p = 0; p < PX; p++) {
-            double g11 = acc[0][p] * scale, g12 = acc[1][p] * scale, g22 = acc[2][p] * scale, h1 = acc[3][p] * scale,
-                   h2 = acc[4][p] * scale;
-            double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
-            f[p].x = (float)((g11 * h2 - g12 * h1) * idet);
-            f[p].y = (float)((g22 * h1 - g12 * h2) * idet);
-        }
-        sF4[(ty * FP + lx0) / 2] = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
-        sF4[(ty * FP + lx0) / 2 + 1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
-    }
-    __syncthreads();
-    // two adjacent pixels per lane: 16-byte flow stores, 8-byte R0 loads / M stores / R1 gathers --
-    // half the vector-memory instructions of a pixel-per-lane mapping (they, not bytes, bound this
-    // phase).  32 lanes span the tile row, the workgroup covers 8 rows per pass.
-    const int lx = 2 * (tid & 31), x = x0 + lx;
-    if (x >= w) return;
-    const bool second = x + 1 < w;
-    float *Mo = Mout + (size_t)b * M_stride;
-    // branch-free over the lane's rows (clamped loads, predicated stores): all gathers in flight
-#pragma unroll
-    for (int k = 0; k < TH / 8; k++) {
-        const int ly = (tid >> 5) + 8 * k;
-        const bool in = y0 + ly < h;
-        const int y = min(y0 + ly, h - 1);
-        const float4 ff = sF4[(ly * FP + lx) >> 1];
-        const float2 f0 = make_float2(ff.x, ff.y), f1 = make_float2(ff.z, ff.w);
-        const size_t o = (size_t)y * w + x;
-        if (in) {
-            if (second) {
-                ffl_f4u t;
-                t.x = ff.x; t.y = ff.y; t.z = ff.z; t.w = ff.w;
-                *reinterpret_cast<ffl_f4u *>(flow + o) = t;
-            } else {
-                flow[o] = f0;
             }
         }
-        if (UPDATE) ffl_um_pair(R0, R1, plane, w, h, x, y, f0, f1, second, in, Mo);
+
+        // ---- solve (+ fused UpdateMatrices) -----------------------------------------------------------
+        // The solved displacements are transposed through LDS (aliasing the column-sum buffer) so that
+        // the global phase below runs with lanes along x: 512-B flow rows per wave store, and the
+        // bilinear gathers of R1 by neighbouring lanes fall into neighbouring addresses.
+        __syncthreads();  // every lane has finished reading the column sums
+        {
+            float2 f[PX];
+#pragma unroll
+            for (int p = 0; p < PX; p++) {
+                double g11 = acc[0][p] * scale, g12 = acc[1][p] * scale, g22 = acc[2][p] * scale,
+                       h1 = acc[3][p] * scale, h2 = acc[4][p] * scale;
+                double idet = 1.0 / (g11 * g22 - g12 * g12 + 1e-3);
+                f[p].x = (float)((g11 * h2 - g12 * h1) * idet);
+                f[p].y = (float)((g22 * h1 - g12 * h2) * idet);
+            }
+            sF4[(ty * FP + lx0) / 2] = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
+            sF4[(ty * FP + lx0) / 2 + 1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
+        }
+        __syncthreads();
+        // two adjacent pixels per lane: 16-byte flow stores, 8-byte R0 loads / M stores / R1 gathers --
+        // half the vector-memory instructions of a pixel-per-lane mapping.  32 lanes span the tile row,
+        // the workgroup covers 8 rows per pass.
+        const int lx = 2 * (tid & 31), x = x0 + lx;
+        if (x < w) {
+            const bool second = x + 1 < w;
+            // branch-free over the lane's rows (clamped loads, predicated stores): all gathers in flight
+#pragma unroll
+            for (int k = 0; k < TH / 8; k++) {
+                const int ly = (tid >> 5) + 8 * k;
+                const bool in = y0 + ly < h;
+                const int y = min(y0 + ly, h - 1);
+                const float4 ff = sF4[(ly * FP + lx) >> 1];
+                const float2 f0 = make_float2(ff.x, ff.y), f1 = make_float2(ff.z, ff.w);
+                const size_t o = (size_t)y * w + x;
+                if (in) {
+                    if (second) {
+                        ffl_f4u t;
+                        t.x = ff.x; t.y = ff.y; t.z = ff.z; t.w = ff.w;
+                        *reinterpret_cast<ffl_f4u *>(flow + o) = t;
+                    } else {
+                        flow[o] = f0;
+                    }
+                }
+                if (UPDATE) ffl_um_pair(R0, R1, plane, w, h, x, y, f0, f1, second, in, Mo);
+            }
+        }
+        __syncthreads();  // sF has been read: the next tile's column sums may overwrite it
     }
+}
+
+// tiles a workgroup walks down: as many as still leave the device about four rounds of workgroups
+// (1080p, B = 8, level 0: 4 -> 310 / 128 us fused / un-fused against 334 / 145 us with one tile per
+// workgroup; with fewer workgroups than that the coarse levels lose more to idle CUs than they gain)
+static int ffl_blur_rows_per_wg(int tiles_x, int tiles_y, int nB) {
+    int nrb = 8;
+    while (nrb > 1 && (long)tiles_x * ((tiles_y + nrb - 1) / nrb) * nB < 4000) nrb >>= 1;
+    return nrb;
 }
 
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
                            size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st) {
-    dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + 15) / 16, nB));
+    const int tiles_x = (lw + 63) / 64, tiles_y = (lh + 15) / 16;
+    const int nrb = g_blur_rows > 0 ? g_blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB);
+    dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (update)
         hipLaunchKernelGGL((k_blur_solve<true>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
-                           lh);
+                           lh, nrb);
     else
         hipLaunchKernelGGL((k_blur_solve<false>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
-                           lh);
+                           lh, nrb);
 }
