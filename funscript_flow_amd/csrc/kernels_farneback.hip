@@ -265,12 +265,95 @@ __global__ __launch_bounds__(256) void k_pyr_fused3(const uint8_t *__restrict__ 
     }
 }
 
+// The same, four adjacent output pixels per lane (w and lw multiples of 4): the 4S + 2 source bytes of a
+// row come with ONE 12- / 16-byte load and the four results leave with one 16-byte store -- a sixth of
+// the vector-memory instructions of the pixel-per-lane kernel above, which spent its time issuing them.
+template <int S, int FR>
+__global__ __launch_bounds__(256) void k_pyr_fused3x4(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
+                                                      int w, int h, int lw, int lh, GaussKernel gk,
+                                                      float *__restrict__ I, size_t I_stride) {
+    constexpr int NR = S * FR + 2;   // source rows per lane
+    constexpr int NBY = 4 * S + 2;   // source bytes per row: columns cx-1 .. cx+4S
+    const int dx = 4 * (blockIdx.x * 256 + threadIdx.x), u = blockIdx.z;
+    if (dx >= lw) return;
+    const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
+    const int cx = S * dx;  // first sampled column, a multiple of 4
+    const bool wide = cx >= 4 && cx + 4 * S + 4 <= w;  // the aligned words cx-4 .. cx+4S+3 are inside the row
+    const float k0 = gk.k[1], k1 = gk.k[2];
+    const int dy0 = blockIdx.y * FR;
+    float H[NR][4 * S];  // horizontal blur at columns cx .. cx+4S-1
+#pragma unroll
+    for (int j = 0; j < NR; j++) {
+        const int sy = ffl_reflect101(min(S * dy0 - 1 + j, h + 1), h);  // rows past the image are never used
+        const uint8_t *row = img + (size_t)sy * w;
+        float b[NBY];
+        if (wide) {
+            uint32_t wd[S + 2];
+            if (S == 1) {
+                struct __attribute__((packed, aligned(4))) u3 { uint32_t a, b, c; };
+                const u3 t = *reinterpret_cast<const u3 *>(row + cx - 4);
+                wd[0] = t.a; wd[1] = t.b; wd[2] = t.c;
+            } else {
+                struct __attribute__((packed, aligned(4))) u4 { uint32_t a, b, c, d; };
+                const u4 t = *reinterpret_cast<const u4 *>(row + cx - 4);
+                wd[0] = t.a; wd[1] = t.b; wd[2] = t.c; wd[3] = t.d;
+            }
+            b[0] = (float)(wd[0] >> 24);  // column cx-1
+#pragma unroll
+            for (int t = 0; t < 4 * S; t++) b[1 + t] = (float)((wd[1 + (t >> 2)] >> (8 * (t & 3))) & 255u);
+            b[NBY - 1] = (float)(wd[S + 1] & 255u);  // column cx+4S
+        } else {
+#pragma unroll
+            for (int t = 0; t < NBY; t++) b[t] = (float)row[ffl_reflect101(cx - 1 + t, w)];
+        }
+#pragma unroll
+        for (int c = 0; c < 4 * S; c++) H[j][c] = k0 * b[c + 1] + k1 * (b[c] + b[c + 2]);
+    }
+#pragma unroll
+    for (int o = 0; o < FR; o++) {
+        const int dy = dy0 + o;
+        if (dy >= lh) break;
+        const int c = S * o + 1;  // local index of source row S*dy
+        float out[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (S == 1) {
+                const float v00 = k0 * H[c][i] + k1 * (H[c - 1][i] + H[c + 1][i]);
+                out[i] = (v00 * 1.f + 0.f * 0.f) * 1.f + 0.f * 0.f;
+            } else {
+                const float v00 = k0 * H[c][2 * i] + k1 * (H[c - 1][2 * i] + H[c + 1][2 * i]);
+                const float v01 = k0 * H[c][2 * i + 1] + k1 * (H[c - 1][2 * i + 1] + H[c + 1][2 * i + 1]);
+                const float v10 = k0 * H[c + 1][2 * i] + k1 * (H[c][2 * i] + H[c + 2][2 * i]);
+                const float v11 = k0 * H[c + 1][2 * i + 1] + k1 * (H[c][2 * i + 1] + H[c + 2][2 * i + 1]);
+                const float t0 = v00 * 0.5f + v01 * 0.5f, t1 = v10 * 0.5f + v11 * 0.5f;
+                out[i] = t0 * 0.5f + t1 * 0.5f;
+            }
+        }
+        ffl_f4u t;
+        t.x = out[0]; t.y = out[1]; t.z = out[2]; t.w = out[3];
+        *reinterpret_cast<ffl_f4u *>(I + (size_t)u * I_stride + (size_t)dy * lw + dx) = t;
+    }
+}
+
 size_t ffl_pyr_tmp_floats(int w, int h, int lw) { return (size_t)h * lw * (lw != w ? 2 : 1); }
 
 void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, int lw, int lh,
                           GaussKernel gk, float *tmp, size_t tmp_stride, float *I, size_t I_stride, hipStream_t st) {
     const int r = gk.ksize / 2, nq = lw != w ? 2 : 1;
     const double sx = (double)w / lw, sy = (double)h / lh;
+    if (r == 1 && ((lw == w && lh == h) || (w == 2 * lw && h == 2 * lh)) && (lw & 3) == 0 && (w & 3) == 0) {
+        constexpr int FR1 = 4, FR2 = 2;  // output rows per lane (H values held: 6 x 4 and 6 x 8 floats)
+        if (lw == w) {
+            dim3 grid((lw / 4 + 255) / 256, (lh + FR1 - 1) / FR1, nU);
+            hipLaunchKernelGGL((k_pyr_fused3x4<1, FR1>), grid, dim3(256), 0, st, gray_base, gray_stride, ut, w, h, lw, lh,
+                               gk, I, I_stride);
+        } else {
+            dim3 grid((lw / 4 + 255) / 256, (lh + FR2 - 1) / FR2, nU);
+            hipLaunchKernelGGL((k_pyr_fused3x4<2, FR2>), grid, dim3(256), 0, st, gray_base, gray_stride, ut, w, h, lw, lh,
+                               gk, I, I_stride);
+        }
+        return;
+    }
     if (r == 1 && ((lw == w && lh == h) || (w == 2 * lw && h == 2 * lh))) {
         dim3 grid((lw + 255) / 256, (lh + FFL_PYR_FROWS - 1) / FFL_PYR_FROWS, nU);
         if (lw == w)
@@ -305,12 +388,19 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut,
 #define PE_TW 64
 #define PE_TH 16
 #define PE_N FFL_POLY_N
-#define PE_LW (PE_TW + 2 * PE_N)
+#define PE_LW (PE_TW + 2 * PE_N)   // 74 tile columns incl. the halo
+#define PE_LP (PE_LW / 2)          // 37 column pairs
+#define PE_PITCH (PE_LW + 2)       // even row pitch: a pair never straddles an 8-byte boundary
 
+// Two horizontally adjacent pixels per lane in every phase: the tile comes in with 8-byte loads, the
+// vertical pass reads / writes LDS 8 bytes at a time and its float arithmetic pairs up into packed
+// (v_pk_*) instructions, the horizontal pass fetches both pixels' taps with one LDS instruction and
+// stores 8 bytes per plane.  The kernel is VALU-bound (f32 taps + f64 accumulators), so instruction
+// count is what this buys.
 __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, size_t I_stride, float *__restrict__ R,
                                                  size_t R_stride, size_t plane, int w, int h, PolyConsts pc) {
-    __shared__ float sI[PE_TH + 2 * PE_N][PE_LW];
-    __shared__ float sV[3][PE_TH][PE_LW + 1];
+    __shared__ __attribute__((aligned(8))) float sI[PE_TH + 2 * PE_N][PE_PITCH];
+    __shared__ __attribute__((aligned(8))) float sV[3][PE_TH][PE_PITCH];
     const int tid = threadIdx.x;
     const int u = blockIdx.z;
     const int x0 = blockIdx.x * PE_TW, y0 = blockIdx.y * PE_TH;
@@ -318,14 +408,22 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, si
 
     // fixed trip counts (+ a bounds predicate) so that the loops unroll: a rolled loop issues one
     // global load, waits for it, stores it to LDS, and only then issues the next
-    constexpr int N_IN = (PE_TH + 2 * PE_N) * PE_LW, N_V = PE_TH * PE_LW, N_OUT = PE_TH * PE_TW;
+    constexpr int N_IN = (PE_TH + 2 * PE_N) * PE_LP, N_V = PE_TH * PE_LP, N_OUT = PE_TH * (PE_TW / 2);
 #pragma unroll
     for (int it = 0; it < (N_IN + 255) / 256; it++) {
         const int i = tid + 256 * it;
         if (i < N_IN) {
-            int ly = i / PE_LW, lx = i - ly * PE_LW;
-            int gy = min(max(y0 + ly - PE_N, 0), h - 1), gx = min(max(x0 + lx - PE_N, 0), w - 1);
-            sI[ly][lx] = img[(size_t)gy * w + gx];
+            const int ly = i / PE_LP, lx = 2 * (i - ly * PE_LP);
+            const int gy = min(max(y0 + ly - PE_N, 0), h - 1), gx = x0 + lx - PE_N;
+            const float *row = img + (size_t)gy * w;
+            float2 t;
+            if (gx >= 0 && gx + 1 < w) {
+                const ffl_f2u q = *reinterpret_cast<const ffl_f2u *>(row + gx);
+                t = make_float2(q.x, q.y);
+            } else {  // REPLICATE border
+                t = make_float2(row[min(max(gx, 0), w - 1)], row[min(max(gx + 1, 0), w - 1)]);
+            }
+            *reinterpret_cast<float2 *>(&sI[ly][lx]) = t;
         }
     }
     __syncthreads();
@@ -335,20 +433,21 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, si
     for (int it = 0; it < (N_V + 255) / 256; it++) {
         const int i = tid + 256 * it;
         if (i >= N_V) break;
-        int ly = i / PE_LW, lx = i - ly * PE_LW;
-        float c = sI[ly + PE_N][lx];
-        float r0 = c * pc.g[0], r1 = 0.f, r2 = 0.f;
+        const int ly = i / PE_LP, lx = 2 * (i - ly * PE_LP);
+        const float2 c = *reinterpret_cast<const float2 *>(&sI[ly + PE_N][lx]);
+        float2 r0 = make_float2(c.x * pc.g[0], c.y * pc.g[0]), r1 = make_float2(0.f, 0.f), r2 = make_float2(0.f, 0.f);
 #pragma unroll
         for (int k = 1; k <= PE_N; k++) {
-            float a = sI[ly + PE_N - k][lx], b = sI[ly + PE_N + k][lx];
-            float p = a + b;
-            r0 = r0 + pc.g[k] * p;
-            r1 = r1 + pc.xg[k] * (b - a);
-            r2 = r2 + pc.xxg[k] * p;
+            const float2 a = *reinterpret_cast<const float2 *>(&sI[ly + PE_N - k][lx]);
+            const float2 b = *reinterpret_cast<const float2 *>(&sI[ly + PE_N + k][lx]);
+            const float2 p = make_float2(a.x + b.x, a.y + b.y), d = make_float2(b.x - a.x, b.y - a.y);
+            r0 = make_float2(r0.x + pc.g[k] * p.x, r0.y + pc.g[k] * p.y);
+            r1 = make_float2(r1.x + pc.xg[k] * d.x, r1.y + pc.xg[k] * d.y);
+            r2 = make_float2(r2.x + pc.xxg[k] * p.x, r2.y + pc.xxg[k] * p.y);
         }
-        sV[0][ly][lx] = r0;
-        sV[1][ly][lx] = r1;
-        sV[2][ly][lx] = r2;
+        *reinterpret_cast<float2 *>(&sV[0][ly][lx]) = r0;
+        *reinterpret_cast<float2 *>(&sV[1][ly][lx]) = r1;
+        *reinterpret_cast<float2 *>(&sV[2][ly][lx]) = r2;
     }
     __syncthreads();
 
@@ -357,29 +456,70 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, si
 #pragma unroll
     for (int it = 0; it < N_OUT / 256; it++) {
         const int i = tid + 256 * it;
-        int ly = i / PE_TW, lx = i - ly * PE_TW;
-        int x = x0 + lx, y = y0 + ly;
+        const int ly = i / (PE_TW / 2), lx = 2 * (i - ly * (PE_TW / 2));
+        const int x = x0 + lx, y = y0 + ly;
         if (x >= w || y >= h) continue;
         const float *v0 = &sV[0][ly][lx + PE_N], *v1 = &sV[1][ly][lx + PE_N], *v2 = &sV[2][ly][lx + PE_N];
-        float g0 = pc.g[0];
-        double b1 = (double)(v0[0] * g0), b2 = 0, b3 = (double)(v1[0] * g0), b4 = 0, b5 = (double)(v2[0] * g0), b6 = 0;
+        double b1[2], b2[2], b3[2], b4[2], b5[2], b6[2];
+        const float g0c = pc.g[0];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            b1[e] = (double)(v0[e] * g0c);
+            b2[e] = 0;
+            b3[e] = (double)(v1[e] * g0c);
+            b4[e] = 0;
+            b5[e] = (double)(v2[e] * g0c);
+            b6[e] = 0;
+        }
 #pragma unroll
         for (int k = 1; k <= PE_N; k++) {
-            double tg = (double)(v0[k] + v0[-k]);
-            g0 = pc.g[k];
-            b1 += tg * pc.gd[k];
-            b4 += tg * pc.xxgd[k];
-            b2 += (double)((v0[k] - v0[-k]) * pc.xg[k]);
-            b3 += (double)((v1[k] + v1[-k]) * g0);
-            b6 += (double)((v1[k] - v1[-k]) * pc.xg[k]);
-            b5 += (double)((v2[k] + v2[-k]) * g0);
+            const float gk = pc.g[k], xgk = pc.xg[k];
+            // both pixels' taps: v[k], v[k+1] and v[-k], v[-k+1]
+            const float p0[2] = {v0[k], v0[k + 1]}, m0[2] = {v0[-k], v0[-k + 1]};
+            const float p1[2] = {v1[k], v1[k + 1]}, m1[2] = {v1[-k], v1[-k + 1]};
+            const float p2[2] = {v2[k], v2[k + 1]}, m2[2] = {v2[-k], v2[-k + 1]};
+            float s0[2], d0[2], s1[2], d1[2], s2[2];
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                s0[e] = p0[e] + m0[e];
+                d0[e] = (p0[e] - m0[e]) * xgk;
+                s1[e] = (p1[e] + m1[e]) * gk;
+                d1[e] = (p1[e] - m1[e]) * xgk;
+                s2[e] = (p2[e] + m2[e]) * gk;
+            }
+#pragma unroll
+            for (int e = 0; e < 2; e++) {
+                const double tg = (double)s0[e];
+                b1[e] += tg * pc.gd[k];
+                b4[e] += tg * pc.xxgd[k];
+                b2[e] += (double)d0[e];
+                b3[e] += (double)s1[e];
+                b6[e] += (double)d1[e];
+                b5[e] += (double)s2[e];
+            }
         }
-        size_t o = (size_t)y * w + x;
-        out[o] = (float)(b3 * pc.ig11);
-        out[plane + o] = (float)(b2 * pc.ig11);
-        out[2 * plane + o] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
-        out[3 * plane + o] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
-        out[4 * plane + o] = (float)(b6 * pc.ig55);
+        float o[5][2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            o[0][e] = (float)(b3[e] * pc.ig11);
+            o[1][e] = (float)(b2[e] * pc.ig11);
+            o[2][e] = (float)(b1[e] * pc.ig03 + b5[e] * pc.ig33);
+            o[3][e] = (float)(b1[e] * pc.ig03 + b4[e] * pc.ig33);
+            o[4][e] = (float)(b6[e] * pc.ig55);
+        }
+        const size_t off = (size_t)y * w + x;
+        if (x + 1 < w) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                ffl_f2u t;
+                t.x = o[c][0];
+                t.y = o[c][1];
+                *reinterpret_cast<ffl_f2u *>(out + c * plane + off) = t;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 5; c++) out[c * plane + off] = o[c][0];
+        }
     }
 }
 
