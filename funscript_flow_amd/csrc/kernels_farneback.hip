@@ -206,6 +206,125 @@ __global__ __launch_bounds__(256) void k_pyr_v(const float *__restrict__ tmp, si
     }
 }
 
+// Resampling levels (nq == 2), compile-time radius: one lane computes BOTH lerp sides of an output
+// column in k_pyr_h2 (their 2R+2 source bytes overlap: one set of word loads, one 8-byte store), and
+// k_pyr_v2 fetches the 2R+2 distinct rows its two vertical sums share once, 8 bytes (both sides) per
+// load -- 10 / 20 loads per output pixel at R = 4 / 9 instead of 36 / 76.  Same operations in the same
+// order as k_pyr_h / k_pyr_v; lanes at the image border fall back to the per-sample form.
+template <int R>
+__global__ __launch_bounds__(256) void k_pyr_h2(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut, int w,
+                                                int h, int lw, double sx, GaussKernel gk, float *__restrict__ tmp,
+                                                size_t tmp_stride) {
+    constexpr int ROWS = ffl_pyr_rows(R);
+    const int d = blockIdx.x * 256 + threadIdx.x, u = blockIdx.z;
+    if (d >= lw) return;
+    int x0, x1;
+    float fx;
+    ffl_resize_coord(d, w, sx, x0, x1, fx);
+    const bool on1 = fx != 0.f;
+    // both samples from one run of aligned words: taps x0-R .. x0+R+1 inside the row, x1 == x0 + 1
+    const bool wide = x1 == x0 + 1 && x0 >= R && x1 + R < w && (w & 3) == 0;
+    const int wfirst = x0 - R, woff = wfirst & 3, wbase = wfirst - woff;
+    int xm[2][R], xp[2][R];
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+#pragma unroll
+        for (int t = 1; t <= R; t++) {
+            xm[q][t - 1] = ffl_reflect101((q ? x1 : x0) - t, w);
+            xp[q][t - 1] = ffl_reflect101((q ? x1 : x0) + t, w);
+        }
+    const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
+    float2 *out = reinterpret_cast<float2 *>(tmp + (size_t)u * tmp_stride) + d;
+    const int ybase = blockIdx.y * ROWS;
+#pragma unroll
+    for (int k = 0; k < ROWS; k++) {
+        const int y = min(ybase + k, h - 1);
+        const uint8_t *row = img + (size_t)y * w;
+        float acc0, acc1 = 0.f;
+        if (wide) {
+            constexpr int NW = (3 + 2 * R + 2 + 3) / 4;
+            const uint32_t *wp = reinterpret_cast<const uint32_t *>(row + wbase);
+            uint32_t wd[NW], a[NW];
+#pragma unroll
+            for (int q2 = 0; q2 < NW; q2++) wd[q2] = wp[q2];
+#pragma unroll
+            for (int q2 = 0; q2 < NW; q2++)
+                a[q2] = q2 + 1 < NW ? __builtin_amdgcn_alignbyte(wd[q2 + 1], wd[q2], woff) : wd[q2] >> (8 * woff);
+            auto tap = [&](int j) { return (float)((a[j >> 2] >> (8 * (j & 3))) & 255u); };
+            acc0 = gk.k[R] * tap(R);
+#pragma unroll
+            for (int t = 1; t <= R; t++) acc0 = acc0 + gk.k[R + t] * (tap(R - t) + tap(R + t));
+            acc1 = gk.k[R] * tap(R + 1);
+#pragma unroll
+            for (int t = 1; t <= R; t++) acc1 = acc1 + gk.k[R + t] * (tap(R + 1 - t) + tap(R + 1 + t));
+        } else {
+            acc0 = gk.k[R] * (float)row[x0];
+#pragma unroll
+            for (int t = 1; t <= R; t++) acc0 = acc0 + gk.k[R + t] * ((float)row[xm[0][t - 1]] + (float)row[xp[0][t - 1]]);
+            if (on1) {
+                acc1 = gk.k[R] * (float)row[x1];
+#pragma unroll
+                for (int t = 1; t <= R; t++)
+                    acc1 = acc1 + gk.k[R + t] * ((float)row[xm[1][t - 1]] + (float)row[xp[1][t - 1]]);
+            }
+        }
+        if (ybase + k < h) out[(size_t)y * lw] = make_float2(acc0, on1 ? acc1 : 0.f);
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_pyr_v2(const float *__restrict__ tmp, size_t tmp_stride, int w, int h, int lw,
+                                                int lh, double sx, double sy, GaussKernel gk, float *__restrict__ I,
+                                                size_t I_stride) {
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), u = blockIdx.z;
+    if (dx >= lw) return;
+    int x0, x1;
+    float a1;
+    ffl_resize_coord(dx, w, sx, x0, x1, a1);
+    const float a0 = 1.f - a1;
+    const float2 *col = reinterpret_cast<const float2 *>(tmp + (size_t)u * tmp_stride) + dx;  // [row * lw]
+    const int dyy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int dy = min(dyy, lh - 1);
+    int y0, y1;
+    float b1;
+    ffl_resize_coord(dy, h, sy, y0, y1, b1);
+    const float b0 = 1.f - b1;
+    float t[2] = {0.f, 0.f};
+    if (y1 == y0 + 1 && y0 >= R && y1 + R < h) {
+        float2 V[2 * R + 2];  // rows y0-R .. y1+R, both lerp sides
+#pragma unroll
+        for (int j = 0; j < 2 * R + 2; j++) V[j] = col[(size_t)(y0 - R + j) * lw];
+#pragma unroll
+        for (int qy = 0; qy < 2; qy++) {
+            if (qy == 1 && b1 == 0.f) break;
+            const int c = R + qy;
+            float v0 = gk.k[R] * V[c].x, v1 = gk.k[R] * V[c].y;
+#pragma unroll
+            for (int j = 1; j <= R; j++) {
+                v0 = v0 + gk.k[R + j] * (V[c - j].x + V[c + j].x);
+                v1 = v1 + gk.k[R + j] * (V[c - j].y + V[c + j].y);
+            }
+            t[qy] = v0 * a0 + (a1 == 0.f ? 0.f : v1) * a1;
+        }
+    } else {
+#pragma unroll
+        for (int qy = 0; qy < 2; qy++) {
+            if (qy == 1 && b1 == 0.f) break;
+            const int cy = qy ? y1 : y0;
+            float2 c = col[(size_t)cy * lw];
+            float v0 = gk.k[R] * c.x, v1 = gk.k[R] * c.y;
+#pragma unroll
+            for (int j = 1; j <= R; j++) {
+                const float2 m = col[(size_t)ffl_reflect101(cy - j, h) * lw], p = col[(size_t)ffl_reflect101(cy + j, h) * lw];
+                v0 = v0 + gk.k[R + j] * (m.x + p.x);
+                v1 = v1 + gk.k[R + j] * (m.y + p.y);
+            }
+            t[qy] = v0 * a0 + (a1 == 0.f ? 0.f : v1) * a1;
+        }
+    }
+    if (dyy < lh) I[(size_t)u * I_stride + (size_t)dy * lw + dx] = t[0] * b0 + t[1] * b1;
+}
+
 // Fused form for the two fine levels of every BASELINE size: 3-tap blur (R = 1) with an exact S = 1
 // (level 0) or S = 2 (level 1) decimation.  One lane produces FROWS consecutive output rows of one
 // output column: the S*FROWS + 2 source rows are fetched word-wise once, blurred horizontally in
@@ -364,6 +483,18 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut,
                                I_stride);
         return;
     }
+#define FFL_PYR_LAUNCH2(RR)                                                                                         \
+    do {                                                                                                            \
+        dim3 gv((lw + 63) / 64, (lh + 3) / 4, nU);                                                                  \
+        dim3 gh((lw + 255) / 256, (h + ffl_pyr_rows(RR) - 1) / ffl_pyr_rows(RR), nU);                               \
+        hipLaunchKernelGGL(k_pyr_h2<RR>, gh, dim3(256), 0, st, gray_base, gray_stride, ut, w, h, lw, sx, gk, tmp,   \
+                           tmp_stride);                                                                             \
+        hipLaunchKernelGGL(k_pyr_v2<RR>, gv, dim3(256), 0, st, tmp, tmp_stride, w, h, lw, lh, sx, sy, gk, I,        \
+                           I_stride);                                                                               \
+    } while (0)
+    if (nq == 2 && r == 4) { FFL_PYR_LAUNCH2(4); return; }
+    if (nq == 2 && r == 9) { FFL_PYR_LAUNCH2(9); return; }
+#undef FFL_PYR_LAUNCH2
 #define FFL_PYR_LAUNCH(RR)                                                                                          \
     do {                                                                                                            \
         dim3 gv((lw + 63) / 64, (lh + 4 * ffl_pyr_vrows(RR) - 1) / (4 * ffl_pyr_vrows(RR)), nU);                    \
