@@ -117,28 +117,49 @@ __device__ __forceinline__ bool ffl_tile_coord(int tiles_x, int tiles_y, int &b,
 struct __attribute__((packed, aligned(4))) ffl_f2u { float x, y; };
 struct __attribute__((packed, aligned(4))) ffl_f4u { float x, y, z, w; };
 
-// update-matrices body shared by the standalone kernel and the fused blur+solve+update kernel.
-// r0[5] are the R0 coefficients of pixel (x, y); the R1 neighbourhood is gathered here, the two
-// horizontally adjacent bilinear corners with one 8-byte load each.
-__device__ __forceinline__ void ffl_um_core(const float (&r0)[5], const float *__restrict__ R1, size_t plane, int w,
-                                            int h, int x, int y, float dx, float dy, float (&out)[5]) {
+// update-matrices body shared by the standalone kernel and the fused blur+solve+update kernel, in three
+// steps so that the R1 neighbourhood can be fetched in more than one way:
+//   ffl_um_locate   where pixel (x, y) displaced by (dx, dy) lands in R1 and its bilinear weights
+//   (gather)        b[c] = a00 * R1c(x1, y1) + a01 * R1c(x1+1, y1) + a10 * R1c(x1, y1+1) + a11 * R1c(x1+1, y1+1)
+//   ffl_um_finish   the polynomial-difference terms, border scaling and the 5 products
+struct UmLoc {
+    int x1, y1;
+    float a00, a01, a10, a11;
+    bool inside;  // all four corners inside the image
+};
+__device__ __forceinline__ UmLoc ffl_um_locate(int w, int h, int x, int y, float dx, float dy) {
+    UmLoc L;
+    float fx = x + dx, fy = y + dy;
+    L.x1 = (int)floorf(fx);
+    L.y1 = (int)floorf(fy);
+    fx -= L.x1;
+    fy -= L.y1;
+    L.inside = (unsigned)L.x1 < (unsigned)(w - 1) && (unsigned)L.y1 < (unsigned)(h - 1);
+    L.a00 = (1.f - fx) * (1.f - fy);
+    L.a01 = fx * (1.f - fy);
+    L.a10 = (1.f - fx) * fy;
+    L.a11 = fx * fy;
+    return L;
+}
+
+// the two horizontally adjacent corners of a row with one 8-byte load each
+__device__ __forceinline__ void ffl_um_gather(const UmLoc &L, const float *__restrict__ R1, size_t plane, int w,
+                                              float (&b)[5]) {
+    const float *p = R1 + (size_t)L.y1 * w + L.x1;
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const ffl_f2u t = *reinterpret_cast<const ffl_f2u *>(p + c * plane);      // (x1, y1), (x1+1, y1)
+        const ffl_f2u u = *reinterpret_cast<const ffl_f2u *>(p + c * plane + w);  // (x1, y1+1), (x1+1, y1+1)
+        b[c] = L.a00 * t.x + L.a01 * t.y + L.a10 * u.x + L.a11 * u.y;
+    }
+}
+
+__device__ __forceinline__ void ffl_um_finish(const float (&r0)[5], const float (&b)[5], bool inside, int w, int h, int x,
+                                              int y, float dx, float dy, float (&out)[5]) {
     // border[5] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} as selects (no runtime-indexed array)
 #define FFL_BORDER(i) ((i) < 2 ? 0.14f : 0.4472f)
-    float fx = x + dx, fy = y + dy;
-    int x1 = (int)floorf(fx), y1 = (int)floorf(fy);
     float r2, r3, r4, r5, r6;
-    fx -= x1;
-    fy -= y1;
-    if ((unsigned)x1 < (unsigned)(w - 1) && (unsigned)y1 < (unsigned)(h - 1)) {
-        float a00 = (1.f - fx) * (1.f - fy), a01 = fx * (1.f - fy), a10 = (1.f - fx) * fy, a11 = fx * fy;
-        const float *p = R1 + (size_t)y1 * w + x1;
-        float b[5];
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            const ffl_f2u t = *reinterpret_cast<const ffl_f2u *>(p + c * plane);      // (x1, y1), (x1+1, y1)
-            const ffl_f2u u = *reinterpret_cast<const ffl_f2u *>(p + c * plane + w);  // (x1, y1+1), (x1+1, y1+1)
-            b[c] = a00 * t.x + a01 * t.y + a10 * u.x + a11 * u.y;
-        }
+    if (inside) {
         r2 = b[0];
         r3 = b[1];
         r4 = (r0[2] + b[2]) * 0.5f;
@@ -169,6 +190,9 @@ __device__ __forceinline__ void ffl_um_core(const float (&r0)[5], const float *_
 
 // Two horizontally adjacent pixels (x, y), (x+1, y) per lane: R0 read and M written with 8-byte
 // accesses.  `second` is false when x+1 is outside the image; `store` predicates the M writes.
+// R1 fetch: neighbouring pixels move almost alike, so the two pixels' corner pairs usually sit in the same
+// two rows within 4 consecutive columns -- then ONE 16-byte load per row and channel serves both pixels
+// (10 loads instead of 20).  The choice is made per wave (all lanes or none), so there is no divergence.
 __device__ __forceinline__ void ffl_um_pair(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,
                                             int w, int h, int x, int y, float2 f0, float2 f1, bool second, bool store,
                                             float *__restrict__ Mo) {
@@ -185,8 +209,28 @@ __device__ __forceinline__ void ffl_um_pair(const float *__restrict__ R0, const 
 #pragma unroll
         for (int c = 0; c < 5; c++) ra[c] = rb[c] = R0[c * plane + o];
     }
-    ffl_um_core(ra, R1, plane, w, h, x, y, f0.x, f0.y, ma);
-    ffl_um_core(rb, R1, plane, w, h, second ? x + 1 : x, y, f1.x, f1.y, mb);
+    const int xb = second ? x + 1 : x;
+    const UmLoc La = ffl_um_locate(w, h, x, y, f0.x, f0.y), Lb = ffl_um_locate(w, h, xb, y, f1.x, f1.y);
+    float ba[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, bb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    const int dxx = Lb.x1 - La.x1;
+    const bool span = La.inside && Lb.inside && La.y1 == Lb.y1 && (unsigned)dxx <= 2u && La.x1 + 3 < w;
+    if (__all(span)) {
+        const float *p = R1 + (size_t)La.y1 * w + La.x1;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            const ffl_f4u t = *reinterpret_cast<const ffl_f4u *>(p + c * plane);      // row y1,   columns x1 .. x1+3
+            const ffl_f4u u = *reinterpret_cast<const ffl_f4u *>(p + c * plane + w);  // row y1+1
+            ba[c] = La.a00 * t.x + La.a01 * t.y + La.a10 * u.x + La.a11 * u.y;
+            const float t0 = dxx == 0 ? t.x : (dxx == 1 ? t.y : t.z), t1 = dxx == 0 ? t.y : (dxx == 1 ? t.z : t.w);
+            const float u0 = dxx == 0 ? u.x : (dxx == 1 ? u.y : u.z), u1 = dxx == 0 ? u.y : (dxx == 1 ? u.z : u.w);
+            bb[c] = Lb.a00 * t0 + Lb.a01 * t1 + Lb.a10 * u0 + Lb.a11 * u1;
+        }
+    } else {
+        if (La.inside) ffl_um_gather(La, R1, plane, w, ba);
+        if (Lb.inside) ffl_um_gather(Lb, R1, plane, w, bb);
+    }
+    ffl_um_finish(ra, ba, La.inside, w, h, x, y, f0.x, f0.y, ma);
+    ffl_um_finish(rb, bb, Lb.inside, w, h, xb, y, f1.x, f1.y, mb);
     if (!store) return;
     if (second) {
 #pragma unroll
