@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
+    ap.add_argument("--zoom", type=float, default=0.0,
+                    help="breathing zoom of the synthetic clip (0 = BASELINE's pure sine-translate); a zooming clip has a "
+                         "spatially varying flow, which the data-dependent gather fast path sees less often")
     ap.add_argument("--blur-rows", type=int, default=0, help="tiles a k_blur_solve workgroup walks down (0 = automatic)")
     ap.add_argument("--trace-steps", action="store_true", help="print per-step host wall times to stderr")
     ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows (fixed at 16)")
@@ -135,7 +138,7 @@ def main():
     W, H, B = args.width, args.height, args.batch
     N = W * H
     U = 2 * B if args.independent else B + 1
-    frames = sine_translate_frames(U, W, H, seed=1 if world == 1 else 10 + rank)
+    frames = sine_translate_frames(U, W, H, seed=1 if world == 1 else 10 + rank, zoom=args.zoom)
     ctx = _capi.Context(W, H, device=local_rank, frame_slots=U + 1, flow_slots=3 * B, max_batch=B)
     for i in range(U):
         ctx.upload_frame(i, frames[i])
