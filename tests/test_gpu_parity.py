@@ -155,3 +155,26 @@ def test_errors_are_loud():
             ctx.pass1_result(0)                       # nothing computed yet
     with pytest.raises(_capi.FFLError):
         _capi.Context(8, 8)
+
+
+@pytest.mark.parametrize("w,h", [(16, 16), (17, 19), (31, 64), (64, 33), (65, 17), (127, 129), (130, 66), (20, 300), (300, 20)])
+def test_small_and_awkward_sizes_bit_exact(w, h):
+    """Sizes below one 64x16 tile, not multiples of 4 / 16 / 64, and extreme aspect ratios: every kernel's edge
+    paths (clamped rows, partial tiles and strips, byte-wise pyramid taps, 1-strip reductions)."""
+    fr = frames(3, w, h, seed=w * 7 + h, amp=(1.5, 1.0), period=5)
+    with _capi.Context(w, h, max_batch=2, frame_slots=4, flow_slots=4) as ctx:
+        for i in range(3):
+            ctx.upload_frame(i, fr[i])
+        ctx.flow_pairs([0, 1], [1, 2], [0, 1])
+        for j in range(2):
+            ref = orc.farneback(fr[j], fr[j + 1])
+            assert np.array_equal(ctx.download_flow(j), ref)
+            x, y, v, mm, _ = ctx.pass1_result(j)
+            ox, oy, ov = orc.max_divergence_np(ref)
+            assert (x, y) == (ox, oy) and np.float32(v).tobytes() == np.float32(ov).tobytes()
+            rm = float(orc.mean_mag_np(ref))
+            assert abs(float(mm) - rm) <= 1e-4 * max(rm, 1e-30)
+            c = (0.37 * w, 0.61 * h)
+            got = ctx.radial([j], [c], [False], False)[0]
+            want = float(orc.radial_np(ref, c, False, False))
+            assert abs(got - want) <= 1e-4 * max(abs(want), float(np.mean(np.abs(ref))) * max(w, h) * 1e-2)
