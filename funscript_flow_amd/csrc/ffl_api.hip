@@ -27,6 +27,7 @@ static int g_num_lanes = 2;  // compute lanes per context created from now on (f
 // Schedule of the frame-only kernels (ffl_set_option "run_ahead", see run_batch).  Measured at 1080p, B = 8
 // (pairs/s with 1 / 2 lanes): 0 serial 3840 / 4063, 2 fork-join 3641 / 4101, 1 run-ahead 3943 / 4159.
 static int g_run_ahead = 0;
+static int g_merge_expand = 1;  // serial schedule: all levels' pyramid + PolyExp in three merged launches
 
 struct ProfRec {
     int cls;
@@ -633,7 +634,48 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
             for (int k = c->levels; k >= 0; k--) HIPCHK(c, hipStreamWaitEvent(st, L.ev_R[k], 0));
     }
     const bool run_ahead = mode == 1;
-    const bool expanded = mode != 0;
+    bool expanded = mode != 0;
+    if (mode == 0 && g_merge_expand && c->levels + 1 <= FFL_MAX_JOBS) {
+        // serial schedule, merged form: the frame-only work of ALL levels up front in three launches
+        // (pyramid phase A + B, PolyExp) instead of ten small ones whose ramps and tails leave the device idle
+        PyrJob pj[FFL_MAX_JOBS];
+        PolyJob qj[FFL_MAX_JOBS];
+        int nj = 0;
+        for (int k = c->levels; k >= 0; k--, nj++) {
+            const LevelGeom &g = c->geom[k];
+            const size_t plane = (size_t)g.lw * g.lh;
+            memset(&pj[nj], 0, sizeof(PyrJob));
+            pj[nj].lw = g.lw;
+            pj[nj].lh = g.lh;
+            pj[nj].gk = g.gk;
+            pj[nj].tmp = L.d_T + L.t_off[k];
+            pj[nj].tmp_stride = ffl_pyr_tmp_floats(c->w, c->h, g.lw);
+            pj[nj].I = L.d_I + L.i_off[k];
+            pj[nj].I_stride = plane;
+            memset(&qj[nj], 0, sizeof(PolyJob));
+            qj[nj].I = L.d_I + L.i_off[k];
+            qj[nj].I_stride = plane;
+            qj[nj].R = L.d_R + L.r_off[k];
+            qj[nj].R_stride = 5 * plane;
+            qj[nj].plane = plane;
+            qj[nj].w = g.lw;
+            qj[nj].h = g.lh;
+        }
+        {
+            ProfScope ps(c, FFL_K_PYRAMID, st);
+            if (!ffl_launch_pyr_multi(c->d_gray, N, ut, nU, c->w, c->h, pj, nj, st))
+                for (int k = c->levels; k >= 0; k--) {  // a level outside the merged kinds: per-level kernels
+                    const LevelGeom &g = c->geom[k];
+                    ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, g.lw, g.lh, g.gk, L.d_T + L.t_off[k],
+                                         ffl_pyr_tmp_floats(c->w, c->h, g.lw), L.d_I + L.i_off[k], (size_t)g.lw * g.lh, st);
+                }
+        }
+        {
+            ProfScope ps(c, FFL_K_POLYEXP, st);
+            ffl_launch_polyexp_multi(qj, nj, nU, c->pc, st);
+        }
+        expanded = true;
+    }
 
     float *cur = L.d_flowA, *prv = L.d_flowB;
     int pw = 0, ph = 0;
@@ -883,6 +925,10 @@ int ffl_set_option(const char *name, int value) {
     if (!name) return FFL_ERR_INVALID;
     if (!strcmp(name, "blur_tile_h")) {  // fixed: the box-sum order is anchored to blocks of 16 rows
         return value == 16 ? FFL_OK : FFL_ERR_INVALID;
+    }
+    if (!strcmp(name, "merge_expand")) {  // 1 (default): merged frame-expansion launches, 0: one set per level
+        g_merge_expand = value != 0;
+        return FFL_OK;
     }
     if (!strcmp(name, "blur_rows")) {  // tiles a k_blur_solve workgroup walks down: 0 automatic, 1..64
         if (value < 0 || value > 64) return FFL_ERR_INVALID;

@@ -55,7 +55,38 @@ struct FrontParams {  // k_frontend: decoded 3-channel frame -> gray crop window
     int mode, rgb;
 };
 
+// merged launches: one 1-D grid cut into per-job block ranges
+#define FFL_MAX_JOBS 4
+enum { FFL_PYR_F1 = 0, FFL_PYR_F2, FFL_PYR_H4, FFL_PYR_H9, FFL_PYR_V4, FFL_PYR_V9 };
+struct PyrJob {  // one level of the pyramid (caller fills lw, lh, gk, tmp, tmp_stride, I, I_stride)
+    int kind, w, h, lw, lh;
+    unsigned gx, gy, first;
+    double sx, sy;
+    float *tmp, *I;
+    size_t tmp_stride, I_stride;
+    GaussKernel gk;
+};
+struct PyrJobs {
+    PyrJob j[FFL_MAX_JOBS];
+    int n;
+};
+struct PolyJob {  // one level of PolyExp (caller fills I, I_stride, R, R_stride, plane, w, h)
+    const float *I;
+    float *R;
+    size_t I_stride, R_stride, plane;
+    int w, h;
+    unsigned gx, gy, first;
+};
+struct PolyJobs {
+    PolyJob j[FFL_MAX_JOBS];
+    int n;
+};
+
 // ---- launchers (each enqueues on `st` and returns; no synchronisation) ----------------------
+// all pyramid levels in two launches; false (nothing launched) when a level needs the generic kernels
+bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, const PyrJob *levels,
+                          int n, hipStream_t st);
+void ffl_launch_polyexp_multi(const PolyJob *levels, int n, int nU, PolyConsts pc, hipStream_t st);
 void ffl_launch_frontend(const uint8_t *src, uint8_t *gray, FrontParams p, hipStream_t st);
 void ffl_launch_gray(const uint8_t *bgr, uint8_t *gray, int n_pixels, hipStream_t st);
 size_t ffl_pyr_tmp_floats(int w, int h, int lw);  // per-frame size of the level's horizontal-pass buffer

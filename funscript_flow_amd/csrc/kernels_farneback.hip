@@ -212,11 +212,11 @@ __global__ __launch_bounds__(256) void k_pyr_v(const float *__restrict__ tmp, si
 // load -- 10 / 20 loads per output pixel at R = 4 / 9 instead of 36 / 76.  Same operations in the same
 // order as k_pyr_h / k_pyr_v; lanes at the image border fall back to the per-sample form.
 template <int R>
-__global__ __launch_bounds__(256) void k_pyr_h2(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut, int w,
+__device__ __forceinline__ void k_pyr_h2_body(const unsigned bx, const unsigned by, const unsigned bz, const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut, int w,
                                                 int h, int lw, double sx, GaussKernel gk, float *__restrict__ tmp,
                                                 size_t tmp_stride) {
     constexpr int ROWS = ffl_pyr_rows(R);
-    const int d = blockIdx.x * 256 + threadIdx.x, u = blockIdx.z;
+    const int d = bx * 256 + threadIdx.x, u = bz;
     if (d >= lw) return;
     int x0, x1;
     float fx;
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256) void k_pyr_h2(const uint8_t *__restrict__ gray
         }
     const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
     float2 *out = reinterpret_cast<float2 *>(tmp + (size_t)u * tmp_stride) + d;
-    const int ybase = blockIdx.y * ROWS;
+    const int ybase = by * ROWS;
 #pragma unroll
     for (int k = 0; k < ROWS; k++) {
         const int y = min(ybase + k, h - 1);
@@ -271,19 +271,25 @@ __global__ __launch_bounds__(256) void k_pyr_h2(const uint8_t *__restrict__ gray
         if (ybase + k < h) out[(size_t)y * lw] = make_float2(acc0, on1 ? acc1 : 0.f);
     }
 }
+template <int R>
+__global__ __launch_bounds__(256) void k_pyr_h2(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut, int w,
+                                                int h, int lw, double sx, GaussKernel gk, float *__restrict__ tmp,
+                                                size_t tmp_stride) {
+    k_pyr_h2_body<R>(blockIdx.x, blockIdx.y, blockIdx.z, gray_base, gray_stride, ut, w, h, lw, sx, gk, tmp, tmp_stride);
+}
 
 template <int R>
-__global__ __launch_bounds__(256) void k_pyr_v2(const float *__restrict__ tmp, size_t tmp_stride, int w, int h, int lw,
+__device__ __forceinline__ void k_pyr_v2_body(const unsigned bx, const unsigned by, const unsigned bz, const float *__restrict__ tmp, size_t tmp_stride, int w, int h, int lw,
                                                 int lh, double sx, double sy, GaussKernel gk, float *__restrict__ I,
                                                 size_t I_stride) {
-    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), u = blockIdx.z;
+    const int dx = bx * 64 + (threadIdx.x & 63), u = bz;
     if (dx >= lw) return;
     int x0, x1;
     float a1;
     ffl_resize_coord(dx, w, sx, x0, x1, a1);
     const float a0 = 1.f - a1;
     const float2 *col = reinterpret_cast<const float2 *>(tmp + (size_t)u * tmp_stride) + dx;  // [row * lw]
-    const int dyy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int dyy = by * 4 + (threadIdx.x >> 6);
     const int dy = min(dyy, lh - 1);
     int y0, y1;
     float b1;
@@ -323,6 +329,12 @@ __global__ __launch_bounds__(256) void k_pyr_v2(const float *__restrict__ tmp, s
         }
     }
     if (dyy < lh) I[(size_t)u * I_stride + (size_t)dy * lw + dx] = t[0] * b0 + t[1] * b1;
+}
+template <int R>
+__global__ __launch_bounds__(256) void k_pyr_v2(const float *__restrict__ tmp, size_t tmp_stride, int w, int h, int lw,
+                                                int lh, double sx, double sy, GaussKernel gk, float *__restrict__ I,
+                                                size_t I_stride) {
+    k_pyr_v2_body<R>(blockIdx.x, blockIdx.y, blockIdx.z, tmp, tmp_stride, w, h, lw, lh, sx, sy, gk, I, I_stride);
 }
 
 // Fused form for the two fine levels of every BASELINE size: 3-tap blur (R = 1) with an exact S = 1
@@ -388,18 +400,18 @@ __global__ __launch_bounds__(256) void k_pyr_fused3(const uint8_t *__restrict__ 
 // row come with ONE 12- / 16-byte load and the four results leave with one 16-byte store -- a sixth of
 // the vector-memory instructions of the pixel-per-lane kernel above, which spent its time issuing them.
 template <int S, int FR>
-__global__ __launch_bounds__(256) void k_pyr_fused3x4(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
+__device__ __forceinline__ void k_pyr_fused3x4_body(const unsigned bx, const unsigned by, const unsigned bz, const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
                                                       int w, int h, int lw, int lh, GaussKernel gk,
                                                       float *__restrict__ I, size_t I_stride) {
     constexpr int NR = S * FR + 2;   // source rows per lane
     constexpr int NBY = 4 * S + 2;   // source bytes per row: columns cx-1 .. cx+4S
-    const int dx = 4 * (blockIdx.x * 256 + threadIdx.x), u = blockIdx.z;
+    const int dx = 4 * (bx * 256 + threadIdx.x), u = bz;
     if (dx >= lw) return;
     const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
     const int cx = S * dx;  // first sampled column, a multiple of 4
     const bool wide = cx >= 4 && cx + 4 * S + 4 <= w;  // the aligned words cx-4 .. cx+4S+3 are inside the row
     const float k0 = gk.k[1], k1 = gk.k[2];
-    const int dy0 = blockIdx.y * FR;
+    const int dy0 = by * FR;
     float H[NR][4 * S];  // horizontal blur at columns cx .. cx+4S-1
 #pragma unroll
     for (int j = 0; j < NR; j++) {
@@ -453,8 +465,86 @@ __global__ __launch_bounds__(256) void k_pyr_fused3x4(const uint8_t *__restrict_
         *reinterpret_cast<ffl_f4u *>(I + (size_t)u * I_stride + (size_t)dy * lw + dx) = t;
     }
 }
+template <int S, int FR>
+__global__ __launch_bounds__(256) void k_pyr_fused3x4(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
+                                                      int w, int h, int lw, int lh, GaussKernel gk,
+                                                      float *__restrict__ I, size_t I_stride) {
+    k_pyr_fused3x4_body<S, FR>(blockIdx.x, blockIdx.y, blockIdx.z, gray_base, gray_stride, ut, w, h, lw, lh, gk, I, I_stride);
+}
 
 size_t ffl_pyr_tmp_floats(int w, int h, int lw) { return (size_t)h * lw * (lw != w ? 2 : 1); }
+
+// All levels' pyramid work in TWO launches (1-D grids cut into per-job ranges): phase A = the fused fine
+// levels + the horizontal passes of the resampling levels, phase B = their vertical passes.  Six small,
+// latency-bound launches (117 us back to back at 1080p) overlap inside two.
+__global__ __launch_bounds__(256) void k_pyr_multi(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
+                                                   PyrJobs jobs) {
+    int i = 0;
+#pragma unroll
+    for (int t = 1; t < FFL_MAX_JOBS; t++)
+        if (t < jobs.n && blockIdx.x >= jobs.j[t].first) i = t;
+    const PyrJob &J = jobs.j[i];
+    const unsigned l = blockIdx.x - J.first, per = J.gx * J.gy;
+    const unsigned bz = l / per, r = l - bz * per, by = r / J.gx, bx = r - by * J.gx;
+    switch (J.kind) {
+        case FFL_PYR_F1: k_pyr_fused3x4_body<1, 4>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.lh, J.gk, J.I, J.I_stride); break;
+        case FFL_PYR_F2: k_pyr_fused3x4_body<2, 2>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.lh, J.gk, J.I, J.I_stride); break;
+        case FFL_PYR_H4: k_pyr_h2_body<4>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.sx, J.gk, J.tmp, J.tmp_stride); break;
+        case FFL_PYR_H9: k_pyr_h2_body<9>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.sx, J.gk, J.tmp, J.tmp_stride); break;
+        case FFL_PYR_V4: k_pyr_v2_body<4>(bx, by, bz, J.tmp, J.tmp_stride, J.w, J.h, J.lw, J.lh, J.sx, J.sy, J.gk, J.I, J.I_stride); break;
+        default: k_pyr_v2_body<9>(bx, by, bz, J.tmp, J.tmp_stride, J.w, J.h, J.lw, J.lh, J.sx, J.sy, J.gk, J.I, J.I_stride); break;
+    }
+}
+
+// kind of merged job a level maps to in phase A (-1: the level needs the generic per-level kernels)
+static int ffl_pyr_kind(int w, int h, int lw, int lh, int ksize) {
+    const int r = ksize / 2;
+    if ((w & 3) || (lw & 3)) return -1;
+    if (r == 1 && lw == w && lh == h) return FFL_PYR_F1;
+    if (r == 1 && w == 2 * lw && h == 2 * lh) return FFL_PYR_F2;
+    if (lw != w && r == 4) return FFL_PYR_H4;
+    if (lw != w && r == 9) return FFL_PYR_H9;
+    return -1;
+}
+
+bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, const PyrJob *lv,
+                          int n, hipStream_t st) {
+    if (n > FFL_MAX_JOBS) return false;
+    PyrJobs A = {}, B = {};
+    unsigned ta = 0, tb = 0;
+    for (int i = 0; i < n; i++) {
+        const int kind = ffl_pyr_kind(w, h, lv[i].lw, lv[i].lh, lv[i].gk.ksize);
+        if (kind < 0) return false;
+        PyrJob J = lv[i];
+        J.w = w;
+        J.h = h;
+        J.sx = (double)w / J.lw;
+        J.sy = (double)h / J.lh;
+        J.kind = kind;
+        if (kind == FFL_PYR_F1 || kind == FFL_PYR_F2) {
+            const int fr = kind == FFL_PYR_F1 ? 4 : 2;
+            J.gx = (J.lw / 4 + 255) / 256;
+            J.gy = (J.lh + fr - 1) / fr;
+        } else {
+            const int rows = ffl_pyr_rows(kind == FFL_PYR_H4 ? 4 : 9);
+            J.gx = (J.lw + 255) / 256;
+            J.gy = (h + rows - 1) / rows;
+            PyrJob V = J;
+            V.kind = kind == FFL_PYR_H4 ? FFL_PYR_V4 : FFL_PYR_V9;
+            V.gx = (J.lw + 63) / 64;
+            V.gy = (J.lh + 3) / 4;
+            V.first = tb;
+            tb += V.gx * V.gy * (unsigned)nU;
+            B.j[B.n++] = V;
+        }
+        J.first = ta;
+        ta += J.gx * J.gy * (unsigned)nU;
+        A.j[A.n++] = J;
+    }
+    hipLaunchKernelGGL(k_pyr_multi, dim3(ta), dim3(256), 0, st, gray_base, gray_stride, ut, A);
+    if (B.n) hipLaunchKernelGGL(k_pyr_multi, dim3(tb), dim3(256), 0, st, gray_base, gray_stride, ut, B);
+    return true;
+}
 
 void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, int lw, int lh,
                           GaussKernel gk, float *tmp, size_t tmp_stride, float *I, size_t I_stride, hipStream_t st) {
@@ -528,13 +618,13 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut,
 // (v_pk_*) instructions, the horizontal pass fetches both pixels' taps with one LDS instruction and
 // stores 8 bytes per plane.  The kernel is VALU-bound (f32 taps + f64 accumulators), so instruction
 // count is what this buys.
-__global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, size_t I_stride, float *__restrict__ R,
+__device__ __forceinline__ void k_polyexp_body(const unsigned bx, const unsigned by, const unsigned bz, const float *__restrict__ I, size_t I_stride, float *__restrict__ R,
                                                  size_t R_stride, size_t plane, int w, int h, PolyConsts pc) {
     __shared__ __attribute__((aligned(8))) float sI[PE_TH + 2 * PE_N][PE_PITCH];
     __shared__ __attribute__((aligned(8))) float sV[3][PE_TH][PE_PITCH];
     const int tid = threadIdx.x;
-    const int u = blockIdx.z;
-    const int x0 = blockIdx.x * PE_TW, y0 = blockIdx.y * PE_TH;
+    const int u = bz;
+    const int x0 = bx * PE_TW, y0 = by * PE_TH;
     const float *img = I + (size_t)u * I_stride;
 
     // fixed trip counts (+ a bounds predicate) so that the loops unroll: a rolled loop issues one
@@ -652,6 +742,37 @@ __global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, si
             for (int c = 0; c < 5; c++) out[c * plane + off] = o[c][0];
         }
     }
+}
+__global__ __launch_bounds__(256) void k_polyexp(const float *__restrict__ I, size_t I_stride, float *__restrict__ R,
+                                                 size_t R_stride, size_t plane, int w, int h, PolyConsts pc) {
+    k_polyexp_body(blockIdx.x, blockIdx.y, blockIdx.z, I, I_stride, R, R_stride, plane, w, h, pc);
+}
+
+// All levels' PolyExp in ONE launch (a 1-D grid cut into per-level ranges): the coarse levels' small grids
+// run inside the level-0 launch instead of paying a launch ramp and tail each.
+__global__ __launch_bounds__(256) void k_polyexp_multi(PolyJobs jobs, PolyConsts pc) {
+    int i = 0;
+#pragma unroll
+    for (int t = 1; t < FFL_MAX_JOBS; t++)
+        if (t < jobs.n && blockIdx.x >= jobs.j[t].first) i = t;
+    const PolyJob &J = jobs.j[i];
+    const unsigned l = blockIdx.x - J.first, per = J.gx * J.gy;
+    const unsigned bz = l / per, r = l - bz * per, by = r / J.gx, bx = r - by * J.gx;
+    k_polyexp_body(bx, by, bz, J.I, J.I_stride, J.R, J.R_stride, J.plane, J.w, J.h, pc);
+}
+
+void ffl_launch_polyexp_multi(const PolyJob *jobs_in, int n, int nU, PolyConsts pc, hipStream_t st) {
+    PolyJobs jobs = {};
+    unsigned total = 0;
+    for (int i = 0; i < n; i++) {
+        jobs.j[i] = jobs_in[i];
+        jobs.j[i].gx = (jobs_in[i].w + PE_TW - 1) / PE_TW;
+        jobs.j[i].gy = (jobs_in[i].h + PE_TH - 1) / PE_TH;
+        jobs.j[i].first = total;
+        total += jobs.j[i].gx * jobs.j[i].gy * (unsigned)nU;
+    }
+    jobs.n = n;
+    hipLaunchKernelGGL(k_polyexp_multi, dim3(total), dim3(256), 0, st, jobs, pc);
 }
 
 void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stride, size_t plane, int nU, int lw,

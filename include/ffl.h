@@ -146,6 +146,9 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
  *   "blur_tile_h" = 16       rows of the 64-wide k_blur_solve LDS tile.  Fixed since the box-sum order
  *                            is anchored to blocks of 16 rows / columns (other values are refused); the
  *                            8 / 16 / 32 sweep of BASELINE configs[2] is recorded in profiles/README.md
+ *   "blur_rows"   = 0..64    tiles a k_blur_solve workgroup walks down (0 = automatic, the default)
+ *   "merge_expand" = 0|1     1 (default): pyramid + PolyExp of all levels in three merged launches per batch;
+ *                            0: one set of launches per level
  *   "lanes"       = 1..4     compute lanes (co-scheduled batches, each on its own stream and work
  *                            buffers) of contexts created afterwards; default 2
  *   "run_ahead"   = 0|1|2    schedule of the frame-only kernels: 0 serial (default), 1 run-ahead on a
