@@ -689,7 +689,9 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
             pt.flow[i] = (k == 0) ? c->d_flow + (size_t)slots[i] * 2 * N : cur + (size_t)i * 2 * plane;
             pt.prev[i] = prv + (size_t)i * 2 * (size_t)pw * ph;
         }
-        if (pw == 0) {  // coarsest level starts from zero flow: one memset when the fields are contiguous
+        // the coarsest level starts from zero flow; nothing reads that field but UpdateMatrices (which is told
+        // so) and the debug capture, so it is only materialised for the latter
+        if (pw == 0 && cap) {
             if (k > 0) HIPCHK(c, hipMemsetAsync(cur, 0, sizeof(float) * 2 * plane * n, st));
             else
                 for (int i = 0; i < n; i++) HIPCHK(c, hipMemsetAsync(pt.flow[i], 0, sizeof(float) * 2 * plane, st));
@@ -700,7 +702,7 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         {
             ProfScope ps(c, FFL_K_UPDATE_MATRICES, st);
             // the x2 upsample of the coarser level's flow (K3) is fused into this launch
-            ffl_launch_update_matrices(Rk, R_stride, plane, pt, n, L.d_M[mi], M_stride, lw, lh, pw, ph, st);
+            ffl_launch_update_matrices(Rk, R_stride, plane, pt, n, L.d_M[mi], M_stride, lw, lh, pw, ph, pw == 0, st);
         }
         bool captured = false;
         auto capture = [&]() -> int {

@@ -788,7 +788,9 @@ void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stri
 // in XCD-aware panel order: the R1 rows y1, y1+1 gathered by vertically adjacent tiles are re-read
 // from L2.  usx / usy = (double)pw / w, (double)ph / h.
 // ------------------------------------------------------------------------------------------------
-template <bool UPSAMPLE>
+// MODE 0: the flow field is read; 1: it is formed here (x2 upsample of the coarser level) and written; 2: it is
+// zero (coarsest level) and neither read nor written -- k_blur_solve overwrites it without reading it
+template <int MODE>
 __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R, size_t R_stride, size_t plane,
                                                          PairTab pt, float *__restrict__ M, size_t M_stride, int w,
                                                          int h, int pw, int ph, double usx, double usy) {
@@ -804,6 +806,7 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
     const float2 *prev = reinterpret_cast<const float2 *>(pt.prev[b]);
     int xa0 = 0, xa1 = 0, xb0 = 0, xb1 = 0;
     float aa1 = 0.f, ab1 = 0.f;
+    constexpr bool UPSAMPLE = MODE == 1;
     if (UPSAMPLE) {
         ffl_resize_coord(x, pw, usx, xa0, xa1, aa1);
         ffl_resize_coord(second ? x + 1 : x, pw, usx, xb0, xb1, ab1);
@@ -850,6 +853,8 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
                     flow[o] = f0;
                 }
             }
+        } else if (MODE == 2) {
+            f0 = f1 = make_float2(0.f, 0.f);
         } else {
             if (second) {
                 const ffl_f4u t = *reinterpret_cast<const ffl_f4u *>(flow + o);
@@ -864,14 +869,17 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
 }
 
 void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
-                                size_t M_stride, int lw, int lh, int pw, int ph, hipStream_t st) {
+                                size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, hipStream_t st) {
     dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + 15) / 16, nB));
     if (pw > 0)
-        hipLaunchKernelGGL(k_update_matrices<true>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
+        hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
                            pw, ph, (double)pw / lw, (double)ph / lh);
+    else if (zero_flow)
+        hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh, 0, 0,
+                           1.0, 1.0);
     else
-        hipLaunchKernelGGL(k_update_matrices<false>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
-                           0, 0, 1.0, 1.0);
+        hipLaunchKernelGGL(k_update_matrices<0>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh, 0, 0,
+                           1.0, 1.0);
 }
 
 // ------------------------------------------------------------------------------------------------
