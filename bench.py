@@ -262,7 +262,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             threads = min(os.cpu_count() or 1, 16)
-            npairs = args.cpu_pairs or threads
+            npairs = args.cpu_pairs or 2 * threads   # ~20 s of CPU work at 1080p (0.6 s per pair and core)
             v, cdt = cpu_baseline(frames, threads, npairs)
             out["cpu_baseline"] = {"value": v, "unit": "pairs/s", "cores": threads, "kind": "port",
                                    "sample": f"{npairs} pairs of the same {W}x{H} stream, one pair per thread, "
