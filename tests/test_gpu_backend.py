@@ -244,3 +244,30 @@ def test_ragged_and_minimum_sizes():
             assert ctx.num_levels() == orc.num_levels(w, h)
             ctx.submit_pair(0, fr[0], fr[1])
             assert np.array_equal(ctx.download_flow(0), orc.farneback(fr[0], fr[1])), (w, h)
+
+
+def test_long_stream_recycles_every_ring_and_slot():
+    """400 pairs in batches of 4 with two compute lanes: every event ring (16 / 32 entries), frame slot and flow
+    slot is recycled many times while batches are in flight; the scalars must equal a one-lane, one-batch-at-a-
+    time run of the same clip (which the shorter tests pin against the oracle)."""
+    w, h, n = 128, 96, 400
+    fr = sine_translate_frames(n + 1, w, h, seed=77, amp=(3.0, 2.0), period=23, zoom=0.02)
+    out = []
+    try:
+        for lanes, run_ahead, merge in [(1, 0, 1), (2, 0, 1), (2, 1, 0), (3, 2, 1)]:
+            _capi.set_option("lanes", lanes)
+            _capi.set_option("run_ahead", run_ahead)
+            _capi.set_option("merge_expand", merge)
+            with _capi.Context(w, h, max_batch=4, frame_slots=10, flow_slots=3 * 4 + 13) as ctx:
+                dots, recs = pipeline.PairEngine(ctx).process_chunk(fr)
+            out.append((np.array(dots), [tuple(r) for r in recs]))
+    finally:
+        _capi.set_option("lanes", 2)
+        _capi.set_option("run_ahead", 0)
+        _capi.set_option("merge_expand", 1)
+    for d, r in out[1:]:
+        assert np.array_equal(d, out[0][0]) and r == out[0][1]
+    j = 123
+    with _capi.Context(w, h, max_batch=1) as ctx:
+        ctx.submit_pair(0, fr[j], fr[j + 1])
+        assert tuple(ctx.pass1_result(0)) == out[0][1][j]
