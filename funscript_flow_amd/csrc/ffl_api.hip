@@ -32,6 +32,7 @@ static int g_merge_expand = 1;  // serial schedule: all levels' pyramid + PolyEx
 struct ProfRec {
     int cls;
     hipEvent_t a, b;
+    bool shared_start;  // `a` is the previous record's `b`
 };
 
 struct LevelGeom {
@@ -108,6 +109,10 @@ struct ffl_ctx {
     // profiling
     unsigned prof_mask = 0;   // bit k set: bracket every launch of kernel class k with HIP events
     std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;   // recycled timing events
+    hipEvent_t prof_last_end = nullptr;  // end event of the latest timed launch, while nothing followed it
+    int prof_last_cls = -1;
+    hipStream_t prof_last_stream = nullptr;
     int prof_launches[FFL_K_COUNT] = {0};
     double prof_ms[FFL_K_COUNT] = {0};
     std::string err;
@@ -234,23 +239,47 @@ static void level_geometry(ffl_ctx *c) {  // FarnebackOpticalFlowImpl::calc leve
 }
 
 // ---- profiling helpers ---------------------------------------------------------------------------
+// Timing events come from a per-context pool (creating two events per launch cost more host time than the
+// launch itself).  A launch that directly follows a timed launch of the same class on the same stream starts
+// at that launch's end event instead of recording one of its own.
+static hipEvent_t prof_event(ffl_ctx *c) {
+    if (!c->prof_pool.empty()) {
+        hipEvent_t e = c->prof_pool.back();
+        c->prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
 struct ProfScope {
     ffl_ctx *c;
     int cls;
     hipEvent_t a = nullptr, b = nullptr;
-    bool on;
+    bool on, shared = false;
     ProfScope(ffl_ctx *c_, int cls_, hipStream_t st) : c(c_), cls(cls_), on((c_->prof_mask >> cls_) & 1u) {
         if (on) {
-            hipEventCreate(&a);
-            hipEventCreate(&b);
-            hipEventRecord(a, st);
             stream = st;
+            if (c->prof_last_end && c->prof_last_cls == cls && c->prof_last_stream == st) {
+                a = c->prof_last_end;  // nothing was queued on `st` since that launch ended
+                shared = true;
+            } else {
+                a = prof_event(c);
+                hipEventRecord(a, st);
+            }
+        } else {
+            c->prof_last_end = nullptr;  // an untimed launch breaks the chain
         }
     }
     ~ProfScope() {
         if (on) {
+            b = prof_event(c);
             hipEventRecord(b, stream);
-            c->prof_recs.push_back({cls, a, b});
+            c->prof_recs.push_back({cls, a, b, shared});
+            c->prof_last_end = b;
+            c->prof_last_cls = cls;
+            c->prof_last_stream = stream;
         }
     }
     hipStream_t stream = nullptr;
@@ -263,10 +292,13 @@ static void prof_collect(ffl_ctx *c) {
         hipEventElapsedTime(&ms, r.a, r.b);
         c->prof_launches[r.cls]++;
         c->prof_ms[r.cls] += ms;
-        hipEventDestroy(r.a);
-        hipEventDestroy(r.b);
+    }
+    for (auto &r : c->prof_recs) {
+        if (!r.shared_start) c->prof_pool.push_back(r.a);
+        c->prof_pool.push_back(r.b);
     }
     c->prof_recs.clear();
+    c->prof_last_end = nullptr;
 }
 
 // ---- API -----------------------------------------------------------------------------------------
@@ -294,6 +326,7 @@ void ffl_destroy(ffl_ctx *c) {
     if (c->s_post) hipStreamSynchronize(c->s_post);
     if (c->s_copy) hipStreamSynchronize(c->s_copy);
     prof_collect(c);
+    for (auto e : c->prof_pool) hipEventDestroy(e);
     for (auto e : c->up_ring)
         if (e) hipEventDestroy(e);
     for (auto e : c->post_ring)
