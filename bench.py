@@ -73,7 +73,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=32,
+                    help="pairs per ffl_flow_pairs call (a step); 32 fills the device at every pyramid level: "
+                         "1080p 4450 / 4700 / 5030 / 4880 pairs/s at B = 8 / 16 / 32 / 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")

@@ -12,7 +12,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o s -- 
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_F -o f -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_W -o w -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 cp profiles/traffic.json /tmp/traffic_prev.json
-python profiles/make_traffic.py $O/${TAG}_F/f_counter_collection.csv $O/${TAG}_W/w_counter_collection.csv k_blur_solve 1920x1080 8
+BATCH=$(python -c "import json; print(json.load(open('$O/${TAG}_bench.json'))['config']['pairs_per_step'])")
+python profiles/make_traffic.py $O/${TAG}_F/f_counter_collection.csv $O/${TAG}_W/w_counter_collection.csv k_blur_solve 1920x1080 $BATCH
 cp profiles/traffic.json $O/${TAG}_traffic.json
 python profiles/summarize_trace.py $O/${TAG}_stats/s_kernel_trace.csv > $O/${TAG}_kernel_trace_by_grid.txt
 cp $O/${TAG}_stats/s_kernel_stats.csv $O/${TAG}_kernel_stats.csv
