@@ -144,8 +144,10 @@ __device__ __forceinline__ bool ffl_tile_coord(int tiles_x, int tiles_y, int &b,
 }
 
 // 8- and 16-byte vectors that are only 4-byte aligned: gfx950 global loads/stores of dwordx2/x4 need
-// dword alignment only, and every vector-memory wave-instruction costs the texture-address unit the
-// same ~16 cycles whatever its width -- halving the instruction count is what speeds these kernels up.
+// dword alignment only.  Wider accesses pay where they cut the number of lane requests to the vector L1
+// (byte taps of the pyramid fetched as words: 54 -> 22 us; one 16-byte R1 load serving two pixels instead
+// of two 8-byte gathers: K5 -7 %); merely halving the instruction count at the same bytes did not
+// (phase V of k_blur_solve with 8-byte loads was slower than with 4-byte loads).
 struct __attribute__((packed, aligned(4))) ffl_f2u { float x, y; };
 struct __attribute__((packed, aligned(4))) ffl_f4u { float x, y, z, w; };
 
