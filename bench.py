@@ -27,20 +27,38 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DOMINANT = "k_blur_solve"  # per profiles/*_kernel_stats.csv; --profile-all re-derives it live
-SIGMA_NK = 1.0 + 0.25 + 0.0625 + 0.015625  # sum of level pixel counts / N for the 4-scale pyramid
 
 
-def alg_bytes_per_batch(N, B, U):
-    """Algorithmic HBM bytes per kernel class for one batch (SURVEY 8d stage graph: every stage
-    reads its inputs once and writes its outputs once, f32 planes)."""
-    s = SIGMA_NK * N
+FUSE_FIRST = 10000  # the library's default threshold; --fuse-first overrides (see ffl_set_option)
+
+
+def alg_bytes_per_batch(N, B, U, level_sizes):
+    """Algorithmic HBM bytes per kernel class for one batch (SURVEY 8d stage graph: every stage reads its inputs
+    once and writes its outputs once, f32 planes).  level_sizes = [(lw, lh)] for k = 0 .. levels.
+
+    SURVEY 8(d): "no cross-stage fusion ... a fused implementation that moves fewer real bytes still reports
+    against B_alg (state real rocprof bytes alongside)".  Per level: flow init / x2 upsample 10 n_k (zero fill
+    8 n_k at the coarsest level), UpdateMatrices_0 68 n_k (R0 20 + R1 20 + flow 8 -> M 20), three iterations
+    3 x (M 20 -> flow 8) + 2 x 68 = 220 n_k.  On the levels where the library folds the flow-init and
+    UpdateMatrices_0 stages into the first blur+solve launch (ffl_set_option "fuse_first": levels with at least
+    that many 64x16 tiles over the batch; their M and flow never reach memory) those stages' bytes are counted on
+    the k_blur_solve class; `roofline.traffic` is the measured traffic."""
+    s = float(sum(lw * lh for lw, lh in level_sizes))
+    um = ks = 0.0
+    for k, (lw, lh) in enumerate(level_sizes):
+        n_k = float(lw * lh)
+        init = (8.0 if k == len(level_sizes) - 1 else 10.0) * n_k + 68.0 * n_k
+        tiles = ((lw + 63) // 64) * ((lh + 15) // 16) * B
+        if FUSE_FIRST > 0 and tiles >= FUSE_FIRST:
+            ks += init
+        else:
+            um += init
+        ks += 220.0 * n_k
     return {
         "k_pyr_level": U * (4 * N + 4 * s),          # u8 full-res read per level + f32 level image write
         "k_polyexp": U * 24 * s,                      # I 4 -> R 20
-        # flow init (x2 upsample: 2 in at quarter res + 8 out; coarsest level is a memset) is fused into
-        # the per-level UpdateMatrices launch: R0 20 + R1 20 + flow 8 -> M 20
-        "k_update_matrices": B * (68 * s + 10 * (s - N / 64.0) + 8 * N / 64.0),
-        "k_blur_solve": B * 220 * s,                  # 3 x (M 20 -> flow 8) + 2 fused UpdateMatrices x 68
+        "k_update_matrices": B * um,
+        "k_blur_solve": B * ks,
         "k_pass1": B * 8 * N,
         "k_radial": B * 8 * N,
     }
@@ -82,6 +100,9 @@ def main():
     ap.add_argument("--zoom", type=float, default=0.0,
                     help="breathing zoom of the synthetic clip (0 = BASELINE's pure sine-translate); a zooming clip has a "
                          "spatially varying flow, which the data-dependent gather fast path sees less often")
+    ap.add_argument("--fuse-first", type=int, default=-1,
+                    help="minimum tiles x pairs of a level for folding its initial UpdateMatrices into the first blur+solve "
+                         "launch (library default 10000; 0: never, 1: always)")
     ap.add_argument("--blur-rows", type=int, default=0, help="tiles a k_blur_solve workgroup walks down (0 = automatic)")
     ap.add_argument("--trace-steps", action="store_true", help="print per-step host wall times to stderr")
     ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows (fixed at 16)")
@@ -127,6 +148,10 @@ def main():
     from funscript_flow_amd.pipeline import SMOOTH_RADIUS
     from funscript_flow_amd.synth import sine_translate_frames
 
+    global FUSE_FIRST
+    if args.fuse_first >= 0:
+        _capi.set_option("fuse_first", args.fuse_first)
+        FUSE_FIRST = args.fuse_first
     if args.blur_rows:
         _capi.set_option("blur_rows", args.blur_rows)
     if args.blur_tile_h:
@@ -142,6 +167,7 @@ def main():
     U = 2 * B if args.independent else B + 1
     frames = sine_translate_frames(U, W, H, seed=1 if world == 1 else 10 + rank, zoom=args.zoom)
     ctx = _capi.Context(W, H, device=local_rank, frame_slots=U + 1, flow_slots=3 * B, max_batch=B)
+    level_sizes = [ctx.level_size(k) for k in range(ctx.num_levels() + 1)]
     for i in range(U):
         ctx.upload_frame(i, frames[i])
     ctx.sync()
@@ -225,7 +251,7 @@ def main():
 
     if rank == 0:
         pairs = world * args.steps * B
-        alg = alg_bytes_per_batch(N, B, U)
+        alg = alg_bytes_per_batch(N, B, U, level_sizes)
         dom = max((k for k in alg), key=lambda k: prof[k][1])
         n_launch, ms = prof[dom]
         achieved = alg[dom] * args.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -252,7 +278,7 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"{W}x{H} synthetic sine-translate frame-pair stream, gray frames resident in HBM",
-                       "pairs_per_step": B, "frames_per_step": U, "levels": 4, "winsize": 15, "iterations": 3,
+                       "pairs_per_step": B, "frames_per_step": U, "levels": len(level_sizes), "winsize": 15, "iterations": 3,
                        "poly_n": 5, "parallelism": f"pair-shard x{world}", "compute_lanes": args.lanes or 1},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,

@@ -27,6 +27,11 @@ static int g_num_lanes = 2;  // compute lanes per context created from now on (f
 // Schedule of the frame-only kernels (ffl_set_option "run_ahead", see run_batch).  Measured at 1080p, B = 8
 // (pairs/s with 1 / 2 lanes): 0 serial 3840 / 4063, 2 fork-join 3641 / 4101, 1 run-ahead 3943 / 4159.
 static int g_run_ahead = 0;
+// a level's initial UpdateMatrices runs inside its first blur+solve launch when the level has at least this many
+// 64x16 tiles over the batch (0: never).  The folded launch saves an M write + read but runs its extra phase at 3
+// workgroups per CU: worth it only where the launch is long enough to be bandwidth-bound (1080p, B = 32: level 0
+// 2093 vs 1018 + 1217 us; level 2 157 vs 65 + 68 us; level 3 138 vs 34 + 45 us)
+static int g_fuse_first = 10000;
 static int g_merge_expand = 1;  // serial schedule: all levels' pyramid + PolyExp in three merged launches
 
 struct ProfRec {
@@ -732,7 +737,10 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         if (run_ahead) HIPCHK(c, hipStreamWaitEvent(st, L.ev_R[k], 0));
         else if (!expanded) expand_level(k, st);
         int mi = 0;
-        {
+        // fuse_first: the level's initial UpdateMatrices (and flow upsample) run inside the first blur+solve
+        // launch; the debug capture wants the initial flow and M in memory, so it keeps the separate launch
+        const bool fuse_first = g_fuse_first > 0 && !cap && (long)((lw + 63) / 64) * ((lh + 15) / 16) * n >= g_fuse_first;
+        if (!fuse_first) {
             ProfScope ps(c, FFL_K_UPDATE_MATRICES, st);
             // the x2 upsample of the coarser level's flow (K3) is fused into this launch
             ffl_launch_update_matrices(Rk, R_stride, plane, pt, n, L.d_M[mi], M_stride, lw, lh, pw, ph, pw == 0, st);
@@ -757,8 +765,11 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
             const int update = it < 2;
             {
                 ProfScope ps(c, FFL_K_BLUR_SOLVE, st);
-                ffl_launch_blur_solve(L.d_M[mi], L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, n, lw, lh,
-                                      update, st);
+                if (it == 0 && fuse_first)
+                    ffl_launch_blur_solve_first(L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, n, lw, lh, pw, ph, st);
+                else
+                    ffl_launch_blur_solve(L.d_M[mi], L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, n, lw, lh,
+                                          update, st);
             }
             if (update) mi ^= 1;
         }
@@ -960,6 +971,11 @@ int ffl_set_option(const char *name, int value) {
     if (!name) return FFL_ERR_INVALID;
     if (!strcmp(name, "blur_tile_h")) {  // fixed: the box-sum order is anchored to blocks of 16 rows
         return value == 16 ? FFL_OK : FFL_ERR_INVALID;
+    }
+    if (!strcmp(name, "fuse_first")) {  // minimum tiles x pairs of a level for the folded first launch; 0: never
+        if (value < 0) return FFL_ERR_INVALID;
+        g_fuse_first = value;
+        return FFL_OK;
     }
     if (!strcmp(name, "merge_expand")) {  // 1 (default): merged frame-expansion launches, 0: one set per level
         g_merge_expand = value != 0;

@@ -102,6 +102,8 @@ void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const
                            size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st);
 
 
+void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane, PairTab pt,
+                                 int nB, int lw, int lh, int pw, int ph, hipStream_t st);
 void ffl_set_blur_rows(int n);  // tiles a k_blur_solve workgroup walks down (0 = automatic)
 
 int ffl_pass1_blocks(int w, int h);
@@ -227,11 +229,13 @@ __device__ __forceinline__ void ffl_um_finish(const float (&r0)[5], const float 
 // R1 fetch: neighbouring pixels move almost alike, so the two pixels' corner pairs usually sit in the same
 // two rows within 4 consecutive columns -- then ONE 16-byte load per row and channel serves both pixels
 // (10 loads instead of 20).  The choice is made per wave (all lanes or none), so there is no divergence.
-__device__ __forceinline__ void ffl_um_pair(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,
-                                            int w, int h, int x, int y, float2 f0, float2 f1, bool second, bool store,
-                                            float *__restrict__ Mo) {
+// the arithmetic of ffl_um_pair without the stores: ma / mb = the 5 products of pixel (x, y) / (x+1, y)
+// (mb = those of (x, y) again when `second` is false)
+__device__ __forceinline__ void ffl_um_pair_values(const float *__restrict__ R0, const float *__restrict__ R1,
+                                                   size_t plane, int w, int h, int x, int y, float2 f0, float2 f1,
+                                                   bool second, float (&ma)[5], float (&mb)[5]) {
     const size_t o = (size_t)y * w + x;
-    float ra[5], rb[5], ma[5], mb[5];
+    float ra[5], rb[5];
     if (second) {
 #pragma unroll
         for (int c = 0; c < 5; c++) {
@@ -265,7 +269,15 @@ __device__ __forceinline__ void ffl_um_pair(const float *__restrict__ R0, const 
     }
     ffl_um_finish(ra, ba, La.inside, w, h, x, y, f0.x, f0.y, ma);
     ffl_um_finish(rb, bb, Lb.inside, w, h, xb, y, f1.x, f1.y, mb);
+}
+
+__device__ __forceinline__ void ffl_um_pair(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,
+                                            int w, int h, int x, int y, float2 f0, float2 f1, bool second, bool store,
+                                            float *__restrict__ Mo) {
+    float ma[5], mb[5];
+    ffl_um_pair_values(R0, R1, plane, w, h, x, y, f0, f1, second, ma, mb);
     if (!store) return;
+    const size_t o = (size_t)y * w + x;
     if (second) {
 #pragma unroll
         for (int c = 0; c < 5; c++) {

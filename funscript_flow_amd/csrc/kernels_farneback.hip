@@ -957,10 +957,15 @@ __device__ __forceinline__ void ffl_box_quarter(const double (&d)[18], double (&
 static int g_blur_rows = 0;  // 0: automatic (ffl_blur_rows_per_wg)
 void ffl_set_blur_rows(int n) { g_blur_rows = n; }
 
-template <bool UPDATE>
-__global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *__restrict__ Min, float *__restrict__ Mout,
-                                                    size_t M_stride, const float *__restrict__ R, size_t R_stride,
-                                                    size_t plane, PairTab pt, int w, int h, int nrb) {
+// FIRST != 0: the level's first iteration with the initial UpdateMatrices folded in -- M is never read from
+// memory: a "phase U" computes it for the 78 tile columns x 16 new rows from R0, R1 and the level's initial
+// flow (FIRST == 1: the x2 upsample of the coarser level's flow, formed on the fly and never stored;
+// FIRST == 2: zero) into LDS, where phase V picks it up.  Thanks to the strip walk only the 14 halo columns
+// are computed redundantly (x1.22), and the level saves one whole M write + read (40 B per pixel) and a launch.
+template <bool UPDATE, int FIRST>
+__global__ __launch_bounds__(256, FIRST ? 3 : FFL_K5_WAVES) void k_blur_solve(
+    const float *__restrict__ Min, float *__restrict__ Mout, size_t M_stride, const float *__restrict__ R, size_t R_stride,
+    size_t plane, PairTab pt, int w, int h, int nrb, int pw, int ph, double usx, double usy) {
     constexpr int TW = 64, TH = 16, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
     constexpr int PX = 4;  // consecutive pixels per lane in phase H
     constexpr int NCARRY = LH - TH;  // rows of a tile's 30 that the tile below needs again
@@ -1000,39 +1005,116 @@ __global__ __launch_bounds__(256, FFL_K5_WAVES) void k_blur_solve(const float *_
     // of a wave (16 rows x 4 blocks, all at the same offset inside their 128-byte block) spread over the banks
     constexpr int FP = TW + 2;
     float4 *sF4 = reinterpret_cast<float4 *>(&sS2[0][0][0]);
+    // phase U staging: M of channels 0..2 aliases the column-sum buffer (consumed before the sums are written),
+    // channels 3, 4 wait in their own 10 KB until the second channel group's phase V
+    constexpr int UP = 80;  // row pitch (floats) of the staged M rows
+    __shared__ float sM34[FIRST ? 2 : 1][FIRST ? TH : 1][FIRST ? UP : 1];
+    float *sM012 = reinterpret_cast<float *>(&sS2[0][0][0]);  // [3][TH][UP]
+    static_assert(GC == 3 || !FIRST, "phase U staging assumes the 3 + 2 channel split");
+    const float2 *prevf = reinterpret_cast<const float2 *>(pt.prev[b]);
+    // M of the tile rows whose phase-V index is jbase .. jbase+nrows-1 (image rows y0-7+jbase ..), all 78 columns
+    // one item = two adjacent tile columns (2p, 2p+1) of one row: 39 x nrows items, two pixels per lane like the
+    // standalone kernel (8-byte R0 loads, shared 16-byte R1 loads); columns clamped into the image that fall on
+    // the same pixel are computed once
+    auto upsampled = [&](int gx, int gy) {  // K3: resize(prevFlow, (w, h), INTER_LINEAR) * 2, as in k_update_matrices<1>
+        int xa0, xa1, ya0, ya1;
+        float a1, b1;
+        ffl_resize_coord(gx, pw, usx, xa0, xa1, a1);
+        ffl_resize_coord(gy, ph, usy, ya0, ya1, b1);
+        const float a0 = 1.f - a1, b0 = 1.f - b1;
+        const float2 *r0p = prevf + (size_t)ya0 * pw, *r1p = prevf + (size_t)ya1 * pw;
+        const float2 p00 = r0p[xa0], p01 = r0p[xa1], p10 = r1p[xa0], p11 = r1p[xa1];
+        float2 f;
+        float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
+        f.x = (t0 * b0 + t1 * b1) * 2.0f;
+        t0 = p00.y * a0 + p01.y * a1;
+        t1 = p10.y * a0 + p11.y * a1;
+        f.y = (t0 * b0 + t1 * b1) * 2.0f;
+        return f;
+    };
+    auto phase_u = [&](int y0, int jbase, int nrows) {
+        constexpr int NP = LW / 2;
+#pragma unroll 1
+        for (int i = tid; i < NP * nrows; i += 256) {
+            const int r = i / NP, tx = 2 * (i - r * NP);
+            const int gy = min(max(y0 - FFL_WIN_R + jbase + r, 0), h - 1);
+            const int xa = min(max(x0 + tx - FFL_WIN_R, 0), w - 1), xb = min(max(x0 + tx + 1 - FFL_WIN_R, 0), w - 1);
+            const bool second = xb == xa + 1;
+            float2 f0 = make_float2(0.f, 0.f), f1 = make_float2(0.f, 0.f);
+            if (FIRST == 1) {
+                f0 = upsampled(xa, gy);
+                f1 = upsampled(xb, gy);
+            }
+            float ma[5], mb[5];
+            ffl_um_pair_values(R0, R1, plane, w, h, xa, gy, f0, f1, second, ma, mb);
+#pragma unroll
+            for (int c = 0; c < 3; c++) *reinterpret_cast<float2 *>(&sM012[(c * TH + r) * UP + tx]) = make_float2(ma[c], mb[c]);
+#pragma unroll
+            for (int c = 3; c < 5; c++) *reinterpret_cast<float2 *>(&sM34[c - 3][r][tx]) = make_float2(ma[c], mb[c]);
+        }
+    };
 
 #pragma unroll 1
     for (int rb = 0; rb < nrb; rb++) {
         const int y0 = (strip_y * nrb + rb) * TH;
         if (y0 >= h) break;
         double acc[5][PX];
+        if (FIRST) {
+            if (rb == 0) {  // the strip's first tile: its 14 upper halo rows go straight into the carry registers
+                phase_u(y0, 0, NCARRY);
+                __syncthreads();
+                if (tid < 3 * LW) {
+#pragma unroll
+                    for (int j = 0; j < NCARRY; j++) carry[0][j] = sM012[(vcc * TH + j) * UP + vtx];
+                }
+                if (tid < 2 * LW) {
+#pragma unroll
+                    for (int j = 0; j < NCARRY; j++) carry[1][j] = sM34[vcc][j][vtx];
+                }
+                __syncthreads();
+            }
+            phase_u(y0, NCARRY, TH);
+            __syncthreads();
+        }
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const int c0 = g * GC, nc = min(GC, 5 - c0);
             // ---- phase V: column sums over 15 rows, one (channel, tile column) per lane ------------
             if (g) __syncthreads();  // the previous group's sums have been consumed
-            if (tid < nc * LW) {
+            const bool vlane = tid < nc * LW;
+            float v[LH];
+            if (vlane) {
                 // wave-uniform 64-bit base (a scalar register pair) + a 32-bit per-lane byte offset: the
                 // global_load saddr form -- no per-lane 64-bit address arithmetic, and the row term is one
                 // 32-bit scalar multiply (a pair's 5 M planes are far below 4 GB)
                 const char *Mbb = reinterpret_cast<const char *>(Mb);
                 const unsigned lane_byte = ((unsigned)((c0 + vcc) * plane) + (unsigned)vgx) * 4u;
-                float v[LH];
-                if (rb == 0) {
+                if (FIRST) {
 #pragma unroll
-                    for (int j = 0; j < NCARRY; j++) {
+                    for (int j = 0; j < NCARRY; j++) v[j] = carry[g][j];
+#pragma unroll
+                    for (int j = 0; j < TH; j++)
+                        v[NCARRY + j] = g == 0 ? sM012[(vcc * TH + j) * UP + vtx] : sM34[vcc][j][vtx];
+                } else {
+                    if (rb == 0) {
+#pragma unroll
+                        for (int j = 0; j < NCARRY; j++) {
+                            const unsigned gy = (unsigned)min(max(y0 + j - FFL_WIN_R, 0), h - 1);
+                            v[j] = *reinterpret_cast<const float *>(Mbb + (gy * pitch + lane_byte));
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NCARRY; j++) v[j] = carry[g][j];
+                    }
+#pragma unroll
+                    for (int j = NCARRY; j < LH; j++) {
                         const unsigned gy = (unsigned)min(max(y0 + j - FFL_WIN_R, 0), h - 1);
                         v[j] = *reinterpret_cast<const float *>(Mbb + (gy * pitch + lane_byte));
                     }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < NCARRY; j++) v[j] = carry[g][j];
                 }
-#pragma unroll
-                for (int j = NCARRY; j < LH; j++) {
-                    const unsigned gy = (unsigned)min(max(y0 + j - FFL_WIN_R, 0), h - 1);
-                    v[j] = *reinterpret_cast<const float *>(Mbb + (gy * pitch + lane_byte));
-                }
+            }
+            if (FIRST && g == 0) __syncthreads();  // the staged rows alias the column sums written next
+            if (vlane) {
 #pragma unroll
                 for (int j = 0; j < NCARRY; j++) carry[g][j] = v[TH + j];
                 double o[TH];
@@ -1132,9 +1214,24 @@ void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const
     const int nrb = g_blur_rows > 0 ? g_blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB);
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (update)
-        hipLaunchKernelGGL((k_blur_solve<true>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
-                           lh, nrb);
+        hipLaunchKernelGGL((k_blur_solve<true, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
+                           lh, nrb, 0, 0, 1.0, 1.0);
     else
-        hipLaunchKernelGGL((k_blur_solve<false>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
-                           lh, nrb);
+        hipLaunchKernelGGL((k_blur_solve<false, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt,
+                           lw, lh, nrb, 0, 0, 1.0, 1.0);
+}
+
+// first iteration of a level with the initial UpdateMatrices folded in (pw > 0: initial flow = x2 upsample of
+// pt.prev, pw x ph; pw == 0: zero flow); writes the solved flow to pt.flow and the next M to Mout
+void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane, PairTab pt,
+                                 int nB, int lw, int lh, int pw, int ph, hipStream_t st) {
+    const int tiles_x = (lw + 63) / 64, tiles_y = (lh + 15) / 16;
+    const int nrb = g_blur_rows > 0 ? g_blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB);
+    dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
+    if (pw > 0)
+        hipLaunchKernelGGL((k_blur_solve<true, 1>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
+                           R_stride, plane, pt, lw, lh, nrb, pw, ph, (double)pw / lw, (double)ph / lh);
+    else
+        hipLaunchKernelGGL((k_blur_solve<true, 2>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
+                           R_stride, plane, pt, lw, lh, nrb, 0, 0, 1.0, 1.0);
 }
