@@ -908,6 +908,12 @@ void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, P
 #ifndef FFL_K5_WAVES
 #define FFL_K5_WAVES 4  // waves per SIMD the register allocator must leave room for (= workgroups per CU)
 #endif
+#ifndef FFL_K5_WAVES_FIRST
+#define FFL_K5_WAVES_FIRST 3
+#endif
+#ifndef FFL_K5_GROUP_FIRST
+#define FFL_K5_GROUP_FIRST 3  // the same for the folded first iteration (2 -> 38 KB of LDS: 4 workgroups per CU)
+#endif
 #ifndef FFL_K5_GROUP
 #define FFL_K5_GROUP 3  // channels that go through LDS together (3 -> 3+2, 2 -> 2+2+1)
 #endif
@@ -963,7 +969,7 @@ void ffl_set_blur_rows(int n) { g_blur_rows = n; }
 // FIRST == 2: zero) into LDS, where phase V picks it up.  Thanks to the strip walk only the 14 halo columns
 // are computed redundantly (x1.22), and the level saves one whole M write + read (40 B per pixel) and a launch.
 template <bool UPDATE, int FIRST>
-__global__ __launch_bounds__(256, FIRST ? 3 : FFL_K5_WAVES) void k_blur_solve(
+__global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) void k_blur_solve(
     const float *__restrict__ Min, float *__restrict__ Mout, size_t M_stride, const float *__restrict__ R, size_t R_stride,
     size_t plane, PairTab pt, int w, int h, int nrb, int pw, int ph, double usx, double usy) {
     constexpr int TW = 64, TH = 16, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
@@ -975,7 +981,7 @@ __global__ __launch_bounds__(256, FIRST ? 3 : FFL_K5_WAVES) void k_blur_solve(
     // make the 64 ds_read_b128 of a phase-H wave (16 rows x 4 blocks, 144 B apart) hit 8 distinct
     // 16-byte bank groups per 8 lanes.
     constexpr int LW2 = 44;
-    constexpr int GC = FFL_K5_GROUP, NG = (5 + GC - 1) / GC;  // channels per LDS pass, passes
+    constexpr int GC = FIRST ? FFL_K5_GROUP_FIRST : FFL_K5_GROUP, NG = (5 + GC - 1) / GC;  // channels per LDS pass, passes
     __shared__ double2 sS2[GC][TH][LW2];
     const int tid = threadIdx.x;
     // A workgroup walks down `nrb` vertically adjacent tiles (a column strip of 64 x 16*nrb pixels) and
@@ -1008,9 +1014,9 @@ __global__ __launch_bounds__(256, FIRST ? 3 : FFL_K5_WAVES) void k_blur_solve(
     // phase U staging: M of channels 0..2 aliases the column-sum buffer (consumed before the sums are written),
     // channels 3, 4 wait in their own 10 KB until the second channel group's phase V
     constexpr int UP = 80;  // row pitch (floats) of the staged M rows
-    __shared__ float sM34[FIRST ? 2 : 1][FIRST ? TH : 1][FIRST ? UP : 1];
-    float *sM012 = reinterpret_cast<float *>(&sS2[0][0][0]);  // [3][TH][UP]
-    static_assert(GC == 3 || !FIRST, "phase U staging assumes the 3 + 2 channel split");
+    __shared__ float sM34[FIRST ? 5 - GC : 1][FIRST ? TH : 1][FIRST ? UP : 1];  // channels GC .. 4
+    float *sM012 = reinterpret_cast<float *>(&sS2[0][0][0]);                     // channels 0 .. GC-1: [GC][TH][UP]
+    static_assert(GC * TH * UP * 4 <= (int)sizeof(sS2), "the first group's staged rows must fit the column sums");
     const float2 *prevf = reinterpret_cast<const float2 *>(pt.prev[b]);
     // M of the tile rows whose phase-V index is jbase .. jbase+nrows-1 (image rows y0-7+jbase ..), all 78 columns
     // one item = two adjacent tile columns (2p, 2p+1) of one row: 39 x nrows items, two pixels per lane like the
@@ -1048,9 +1054,9 @@ __global__ __launch_bounds__(256, FIRST ? 3 : FFL_K5_WAVES) void k_blur_solve(
             float ma[5], mb[5];
             ffl_um_pair_values(R0, R1, plane, w, h, xa, gy, f0, f1, second, ma, mb);
 #pragma unroll
-            for (int c = 0; c < 3; c++) *reinterpret_cast<float2 *>(&sM012[(c * TH + r) * UP + tx]) = make_float2(ma[c], mb[c]);
+            for (int c = 0; c < GC; c++) *reinterpret_cast<float2 *>(&sM012[(c * TH + r) * UP + tx]) = make_float2(ma[c], mb[c]);
 #pragma unroll
-            for (int c = 3; c < 5; c++) *reinterpret_cast<float2 *>(&sM34[c - 3][r][tx]) = make_float2(ma[c], mb[c]);
+            for (int c = GC; c < 5; c++) *reinterpret_cast<float2 *>(&sM34[c - GC][r][tx]) = make_float2(ma[c], mb[c]);
         }
     };
 
@@ -1063,13 +1069,14 @@ __global__ __launch_bounds__(256, FIRST ? 3 : FFL_K5_WAVES) void k_blur_solve(
             if (rb == 0) {  // the strip's first tile: its 14 upper halo rows go straight into the carry registers
                 phase_u(y0, 0, NCARRY);
                 __syncthreads();
-                if (tid < 3 * LW) {
 #pragma unroll
-                    for (int j = 0; j < NCARRY; j++) carry[0][j] = sM012[(vcc * TH + j) * UP + vtx];
-                }
-                if (tid < 2 * LW) {
+                for (int g = 0; g < NG; g++) {
+                    const int c0 = g * GC, nc = min(GC, 5 - c0);
+                    if (tid < nc * LW) {
 #pragma unroll
-                    for (int j = 0; j < NCARRY; j++) carry[1][j] = sM34[vcc][j][vtx];
+                        for (int j = 0; j < NCARRY; j++)
+                            carry[g][j] = g == 0 ? sM012[(vcc * TH + j) * UP + vtx] : sM34[c0 - GC + vcc][j][vtx];
+                    }
                 }
                 __syncthreads();
             }
@@ -1094,7 +1101,7 @@ __global__ __launch_bounds__(256, FIRST ? 3 : FFL_K5_WAVES) void k_blur_solve(
                     for (int j = 0; j < NCARRY; j++) v[j] = carry[g][j];
 #pragma unroll
                     for (int j = 0; j < TH; j++)
-                        v[NCARRY + j] = g == 0 ? sM012[(vcc * TH + j) * UP + vtx] : sM34[vcc][j][vtx];
+                        v[NCARRY + j] = g == 0 ? sM012[(vcc * TH + j) * UP + vtx] : sM34[c0 - GC + vcc][j][vtx];
                 } else {
                     if (rb == 0) {
 #pragma unroll
