@@ -254,10 +254,11 @@ def test_long_stream_recycles_every_ring_and_slot():
     fr = sine_translate_frames(n + 1, w, h, seed=77, amp=(3.0, 2.0), period=23, zoom=0.02)
     out = []
     try:
-        for lanes, run_ahead, merge in [(1, 0, 1), (2, 0, 1), (2, 1, 0), (3, 2, 1)]:
+        for lanes, run_ahead, merge, fuse in [(1, 0, 1, 0), (2, 0, 1, 1), (2, 1, 0, 1), (3, 2, 1, 10000)]:
             _capi.set_option("lanes", lanes)
             _capi.set_option("run_ahead", run_ahead)
             _capi.set_option("merge_expand", merge)
+            _capi.set_option("fuse_first", fuse)
             with _capi.Context(w, h, max_batch=4, frame_slots=10, flow_slots=3 * 4 + 13) as ctx:
                 dots, recs = pipeline.PairEngine(ctx).process_chunk(fr)
             out.append((np.array(dots), [tuple(r) for r in recs]))
@@ -265,6 +266,7 @@ def test_long_stream_recycles_every_ring_and_slot():
         _capi.set_option("lanes", 2)
         _capi.set_option("run_ahead", 0)
         _capi.set_option("merge_expand", 1)
+        _capi.set_option("fuse_first", 10000)
     for d, r in out[1:]:
         assert np.array_equal(d, out[0][0]) and r == out[0][1]
     j = 123

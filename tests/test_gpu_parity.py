@@ -178,3 +178,22 @@ def test_small_and_awkward_sizes_bit_exact(w, h):
             got = ctx.radial([j], [c], [False], False)[0]
             want = float(orc.radial_np(ref, c, False, False))
             assert abs(got - want) <= 1e-4 * max(abs(want), float(np.mean(np.abs(ref))) * max(w, h) * 1e-2)
+
+
+@pytest.mark.parametrize("w,h", [(320, 180), (250, 131), (96, 80), (17, 19), (640, 360), (1920, 1080)])
+def test_folded_first_iteration_bit_exact(w, h):
+    """fuse_first = 1: every level's flow init + first UpdateMatrices run inside the first blur+solve launch
+    (phase U into LDS).  By default only levels with >= 10000 tiles over the batch take that path, which no other
+    test reaches -- here it is forced at every level and size, against the oracle."""
+    fr = frames(3, w, h, seed=w + h, amp=(3.0, 2.0), period=6, zoom=0.03)
+    try:
+        _capi.set_option("fuse_first", 1)
+        with _capi.Context(w, h, max_batch=2, frame_slots=4, flow_slots=4) as ctx:
+            for i in range(3):
+                ctx.upload_frame(i, fr[i])
+            ctx.flow_pairs([0, 1], [1, 2], [0, 1])
+            got = [ctx.download_flow(0), ctx.download_flow(1)]
+    finally:
+        _capi.set_option("fuse_first", 10000)
+    for j in range(2):
+        assert np.array_equal(got[j], orc.farneback(fr[j], fr[j + 1]))
