@@ -15,7 +15,7 @@ KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "k_frontend", "k_update_
                   "k_pass1", "k_radial"]
 
 # every symbol include/ffl.h declares (tests check that the library exports all of them)
-EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "ffl_upload_frame", "ffl_upload_frames", "ffl_upload_frames_raw",
+EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "ffl_upload_frame", "ffl_upload_frames", "ffl_upload_frames_raw", "ffl_host_alloc", "ffl_host_free",
            "ffl_flow_pairs",
            "ffl_pass1_result", "ffl_pass1_results", "ffl_radial", "ffl_download_flow", "ffl_upload_flow", "ffl_submit_pair", "ffl_sync",
            "ffl_num_levels", "ffl_level_size", "ffl_download_frame", "ffl_debug_pair", "ffl_set_option", "ffl_profile_enable",
@@ -55,6 +55,8 @@ def load():
     L.ffl_pass1_results.argtypes = [vp, C.c_int, ip, C.c_float, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                     C.POINTER(C.c_float), C.POINTER(C.c_float), ip]
     L.ffl_radial.argtypes = [vp, C.c_int, ip, dp, dp, ip, C.c_int, dp]
+    L.ffl_host_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    L.ffl_host_free.argtypes = [vp, vp]
     L.ffl_download_flow.argtypes = [vp, C.c_int, vp]
     L.ffl_download_frame.argtypes = [vp, C.c_int, vp]
     L.ffl_upload_flow.argtypes = [vp, C.c_int, vp, C.c_int]
@@ -144,6 +146,17 @@ class Context:
         ptrs = (C.c_void_p * len(fr))(*[f.ctypes.data for f in fr])
         self._chk(self.L.ffl_upload_frames(self._h, first_slot, len(fr), ptrs, f0.shape[1], f0.shape[0], ch,
                                            f0.strides[0]))
+
+    def pinned_frames(self, n, channels=1):
+        """(n, height, width[, 3]) uint8 array in page-locked memory of this context (ffl_host_alloc): frames a
+        decoder writes into consecutive entries go to the device without the staging copy.  Do not overwrite an
+        entry before the batch that uses it has returned results (or ctx.sync())."""
+        shape = (n, self.height, self.width) + ((channels,) if channels != 1 else ())
+        nbytes = int(np.prod(shape))
+        p = C.c_void_p()
+        self._chk(self.L.ffl_host_alloc(self._h, nbytes, C.byref(p)))
+        buf = (C.c_uint8 * nbytes).from_address(p.value)
+        return np.frombuffer(buf, np.uint8).reshape(shape)
 
     def upload_frames_raw(self, first_slot, frames, resize, crop=(0, 0), rgb_order=False):
         """Decoded (h, w, 3) uint8 frames -> gray(resize(frame, resize)[crop window]) in consecutive slots

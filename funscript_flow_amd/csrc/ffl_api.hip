@@ -113,6 +113,8 @@ struct ffl_ctx {
     int p1_blocks = 0;
     // profiling
     unsigned prof_mask = 0;   // bit k set: bracket every launch of kernel class k with HIP events
+    // caller-visible page-locked buffers (ffl_host_alloc): uploads out of them skip the staging copy
+    std::vector<std::pair<uint8_t *, size_t>> host_bufs;
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;   // recycled timing events
     hipEvent_t prof_last_end = nullptr;  // end event of the latest timed launch, while nothing followed it
@@ -332,6 +334,7 @@ void ffl_destroy(ffl_ctx *c) {
     if (c->s_copy) hipStreamSynchronize(c->s_copy);
     prof_collect(c);
     for (auto e : c->prof_pool) hipEventDestroy(e);
+    for (auto &hb : c->host_bufs) hipHostFree(hb.first);
     for (auto e : c->up_ring)
         if (e) hipEventDestroy(e);
     for (auto e : c->post_ring)
@@ -466,6 +469,35 @@ int ffl_level_size(const ffl_ctx *c, int level, int *out_wh) {
     return FFL_OK;
 }
 
+static bool in_host_buf(const ffl_ctx *c, const uint8_t *p, size_t bytes) {
+    for (auto &hb : c->host_bufs)
+        if (p >= hb.first && p + bytes <= hb.first + hb.second) return true;
+    return false;
+}
+
+int ffl_host_alloc(ffl_ctx *c, size_t bytes, void **out) {
+    if (!c) return FFL_ERR_INVALID;
+    if (!out || bytes == 0) return set_err(c, FFL_ERR_INVALID, "ffl_host_alloc: bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    uint8_t *p = nullptr;
+    HIPCHK(c, hipHostMalloc(&p, bytes, hipHostMallocDefault));
+    c->host_bufs.push_back({p, bytes});
+    *out = p;
+    return FFL_OK;
+}
+
+int ffl_host_free(ffl_ctx *c, void *ptr) {
+    if (!c) return FFL_ERR_INVALID;
+    for (size_t i = 0; i < c->host_bufs.size(); i++)
+        if (c->host_bufs[i].first == ptr) {
+            HIPCHK(c, hipStreamSynchronize(c->s_copy));  // no transfer may still be reading it
+            HIPCHK(c, hipHostFree(ptr));
+            c->host_bufs.erase(c->host_bufs.begin() + i);
+            return FFL_OK;
+        }
+    return set_err(c, FFL_ERR_INVALID, "ffl_host_free: not a buffer of this context");
+}
+
 // n frames into the consecutive frame slots first..first+n-1: host copies into pinned staging, then ONE
 // H2D transfer (+ one BGR->gray launch) and ONE event for the whole run -- at 256x256 the per-frame
 // runtime calls of a frame-at-a-time upload cost more than the copy itself.
@@ -485,13 +517,17 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
     HIPCHK(c, hipSetDevice(c->device));
     const size_t N = c->N, row = (size_t)width * channels, fbytes = N * channels;
     uint8_t *stage0 = (channels == 1 ? c->h_stage_gray : c->h_stage_bgr) + (size_t)first * fbytes;
+    // frames that sit back to back in one ffl_host_alloc buffer go to the device straight out of it
+    bool direct = (size_t)stride_bytes == row && in_host_buf(c, frames[0], fbytes * n);
+    for (int i = 1; direct && i < n; i++) direct = frames[i] == frames[0] + (size_t)i * fbytes;
     for (int i = 0; i < n; i++) {
         const int fs = first + i;
         // the previous transfer out of this slot's staging areas must have left the host buffer
-        if (c->ev_uploaded[fs]) HIPCHK(c, hipEventSynchronize(c->ev_uploaded[fs]));
+        if (!direct && c->ev_uploaded[fs]) HIPCHK(c, hipEventSynchronize(c->ev_uploaded[fs]));
         uint8_t *stage = stage0 + (size_t)i * fbytes;
         const uint8_t *data = frames[i];
-        if ((size_t)stride_bytes == row) memcpy(stage, data, row * height);
+        if (direct) {
+        } else if ((size_t)stride_bytes == row) memcpy(stage, data, row * height);
         else
             for (int y = 0; y < height; y++) memcpy(stage + (size_t)y * row, data + (ptrdiff_t)y * stride_bytes, row);
         // the device copy of this slot may still be read by batches queued on any lane
@@ -501,11 +537,12 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
         }
     }
     uint8_t *gray = c->d_gray + (size_t)first * N;
+    const uint8_t *src0 = direct ? frames[0] : stage0;
     if (channels == 1) {
-        HIPCHK(c, hipMemcpyAsync(gray, stage0, N * n, hipMemcpyHostToDevice, c->s_copy));
+        HIPCHK(c, hipMemcpyAsync(gray, src0, N * n, hipMemcpyHostToDevice, c->s_copy));
     } else {
         uint8_t *bgr = c->d_bgr + (size_t)first * N * 3;
-        HIPCHK(c, hipMemcpyAsync(bgr, stage0, N * 3 * n, hipMemcpyHostToDevice, c->s_copy));
+        HIPCHK(c, hipMemcpyAsync(bgr, src0, N * 3 * n, hipMemcpyHostToDevice, c->s_copy));
         ProfScope ps(c, FFL_K_GRAY, c->s_copy);
         ffl_launch_gray(bgr, gray, (int)(N * n), c->s_copy);
     }

@@ -89,6 +89,15 @@ int ffl_upload_frames_raw(ffl_ctx *ctx, int first_slot, int n, const uint8_t *co
                           int src_height, ptrdiff_t stride_bytes, int rgb_order, int resize_width, int resize_height,
                           int crop_x, int crop_y);
 
+/* Page-locked host memory owned by the context (freed by ffl_host_free or ffl_destroy).  A decoder that writes its
+ * frames into such a buffer saves the library's staging copy: ffl_upload_frame(s) of tightly packed frames that lie
+ * back to back inside ONE ffl_host_alloc buffer start the H2D transfer straight out of it.  The caller must then
+ * leave those bytes alone until the transfer is over -- after ffl_sync(), or once a result of a batch that uses
+ * the frames has been read (ffl_pass1_result).  Frames anywhere else keep the copy-before-return contract.
+ * (No counterpart in the reference, whose CUDA variant uploads out of pageable ndarrays, FF:986-987.) */
+int ffl_host_alloc(ffl_ctx *ctx, size_t bytes, void **out);
+int ffl_host_free(ffl_ctx *ctx, void *ptr);
+
 /* Queue Farneback flow + pass-1 reductions for n pairs: pair i = (frame fslot0[i], frame fslot1[i])
  * -> flow slot flow_slots[i].  Frames shared between pairs of the batch are expanded once.
  * pov_mode != 0 skips the divergence argmax (FF:880-882).  Asynchronous. */

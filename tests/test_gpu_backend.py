@@ -273,3 +273,24 @@ def test_long_stream_recycles_every_ring_and_slot():
     with _capi.Context(w, h, max_batch=1) as ctx:
         ctx.submit_pair(0, fr[j], fr[j + 1])
         assert tuple(ctx.pass1_result(0)) == out[0][1][j]
+
+
+def test_uploads_out_of_pinned_context_memory():
+    """Frames written into ffl_host_alloc memory (Context.pinned_frames) take the zero-copy upload path (runs of
+    consecutive entries, gray and BGR); results equal those of ordinary ndarrays."""
+    w, h, n = 160, 96, 30
+    fr = sine_translate_frames(n + 1, w, h, seed=5, amp=(2.0, 2.5), period=11)
+    with _capi.Context(w, h, max_batch=4, frame_slots=10, flow_slots=25) as ctx:
+        want = pipeline.PairEngine(ctx).process_chunk(list(fr))
+        pin = ctx.pinned_frames(n + 1)
+        pin[:] = fr
+        got = pipeline.PairEngine(ctx).process_chunk([pin[i] for i in range(n + 1)])
+        assert np.array_equal(got[0], want[0]) and [tuple(r) for r in got[1]] == [tuple(r) for r in want[1]]
+        pin3 = ctx.pinned_frames(3, channels=3)
+        pin3[:] = gray_to_bgr(fr[:3], gains=(0.9, 1.0, 0.8))
+        ctx.upload_frames(0, [pin3[0], pin3[1], pin3[2]])
+        ctx.flow_pairs([0, 1], [1, 2], [0, 1])
+        a = ctx.download_flow(1)
+        ctx.upload_frames(0, [np.array(pin3[i]) for i in range(3)])     # same pixels from pageable memory
+        ctx.flow_pairs([0, 1], [1, 2], [0, 1])
+        assert np.array_equal(a, ctx.download_flow(1))
