@@ -147,11 +147,14 @@ class Context:
         self._chk(self.L.ffl_upload_frames(self._h, first_slot, len(fr), ptrs, f0.shape[1], f0.shape[0], ch,
                                            f0.strides[0]))
 
-    def pinned_frames(self, n, channels=1):
+    def pinned_frames(self, n, channels=1, size=None):
         """(n, height, width[, 3]) uint8 array in page-locked memory of this context (ffl_host_alloc): frames a
         decoder writes into consecutive entries go to the device without the staging copy.  Do not overwrite an
-        entry before the batch that uses it has returned results (or ctx.sync())."""
-        shape = (n, self.height, self.width) + ((channels,) if channels != 1 else ())
+        entry before the batch that uses it has returned results (or ctx.sync()).  `size=(w, h)`: decoded source
+        frames of another size, for upload_frames_raw.  The memory belongs to the context: the array (and every
+        view of it) must not be touched after ctx.close()."""
+        w, h = size if size is not None else (self.width, self.height)
+        shape = (n, h, w) + ((channels,) if channels != 1 else ())
         nbytes = int(np.prod(shape))
         p = C.c_void_p()
         self._chk(self.L.ffl_host_alloc(self._h, nbytes, C.byref(p)))

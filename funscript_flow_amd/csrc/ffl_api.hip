@@ -247,8 +247,8 @@ static void level_geometry(ffl_ctx *c) {  // FarnebackOpticalFlowImpl::calc leve
 
 // ---- profiling helpers ---------------------------------------------------------------------------
 // Timing events come from a per-context pool (creating two events per launch cost more host time than the
-// launch itself).  A launch that directly follows a timed launch of the same class on the same stream starts
-// at that launch's end event instead of recording one of its own.
+// launch itself).  Where the caller knows that timed launches of a class are queued back to back (the three
+// k_blur_solve iterations of a level) a launch starts at its predecessor's end event instead of recording one.
 static hipEvent_t prof_event(ffl_ctx *c) {
     if (!c->prof_pool.empty()) {
         hipEvent_t e = c->prof_pool.back();
@@ -265,10 +265,12 @@ struct ProfScope {
     int cls;
     hipEvent_t a = nullptr, b = nullptr;
     bool on, shared = false;
-    ProfScope(ffl_ctx *c_, int cls_, hipStream_t st) : c(c_), cls(cls_), on((c_->prof_mask >> cls_) & 1u) {
+    // chain: the caller guarantees that nothing was queued on `st` since the previous timed launch of this class
+    ProfScope(ffl_ctx *c_, int cls_, hipStream_t st, bool chain = false)
+        : c(c_), cls(cls_), on((c_->prof_mask >> cls_) & 1u) {
         if (on) {
             stream = st;
-            if (c->prof_last_end && c->prof_last_cls == cls && c->prof_last_stream == st) {
+            if (chain && c->prof_last_end && c->prof_last_cls == cls && c->prof_last_stream == st) {
                 a = c->prof_last_end;  // nothing was queued on `st` since that launch ended
                 shared = true;
             } else {
@@ -599,14 +601,17 @@ int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *fr
         }
         if (!rb.ev) HIPCHK(c, hipEventCreateWithFlags(&rb.ev, hipEventDisableTiming));
         const uint8_t *data = frames[i];
-        if ((size_t)stride_bytes == fp.stride) memcpy(rb.h, data, fbytes);
+        // a tightly packed frame in ffl_host_alloc memory goes to the device straight out of it
+        const bool direct = (size_t)stride_bytes == fp.stride && in_host_buf(c, data, fbytes);
+        if (direct) {
+        } else if ((size_t)stride_bytes == fp.stride) memcpy(rb.h, data, fbytes);
         else
             for (int y = 0; y < sh; y++) memcpy(rb.h + (size_t)y * fp.stride, data + (ptrdiff_t)y * stride_bytes, fp.stride);
         for (size_t l = 0; l < c->lanes.size(); l++) {  // batches still reading the slot's previous frame
             hipEvent_t e = c->ev_last_use[(size_t)fs * c->lanes.size() + l];
             if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
         }
-        HIPCHK(c, hipMemcpyAsync(rb.d, rb.h, fbytes, hipMemcpyHostToDevice, c->s_copy));
+        HIPCHK(c, hipMemcpyAsync(rb.d, direct ? data : rb.h, fbytes, hipMemcpyHostToDevice, c->s_copy));
         {
             ProfScope ps(c, FFL_K_FRONTEND, c->s_copy);
             ffl_launch_frontend(rb.d, c->d_gray + (size_t)fs * c->N, fp, c->s_copy);
@@ -801,7 +806,7 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
             }
             const int update = it < 2;
             {
-                ProfScope ps(c, FFL_K_BLUR_SOLVE, st);
+                ProfScope ps(c, FFL_K_BLUR_SOLVE, st, it > 0 && !cap);  // the three iterations are queued back to back
                 if (it == 0 && fuse_first)
                     ffl_launch_blur_solve_first(L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, n, lw, lh, pw, ph, st);
                 else
