@@ -4,12 +4,15 @@
 //
 // Kernel            roofline   algorithmic bytes / level pixel
 //   k_gray          HBM        4 per full-res pixel (3 in, 1 out)
-//   k_pyr_fused3 /  HBM        1 per full-res pixel in + 4 per level pixel out ("k_pyr_level" class:
-//   k_pyr_h+k_pyr_v            fused 3-tap kernel for exact 1x/2x levels, streaming H+V pair otherwise)
-//   k_polyexp       HBM        24  (4 in, 20 out), 11x11 separable through LDS
+//   k_pyr_*         HBM        1 per full-res pixel in + 4 per level pixel out ("k_pyr_level" class): fused 3-tap
+//                              kernels for the exact 1x / 2x levels (4 pixels per lane), H + V pair for the
+//                              resampling levels; all levels of a batch in two merged launches (k_pyr_multi)
+//   k_polyexp       VALU/HBM   24  (4 in, 20 out), 11x11 separable through LDS, f64 accumulators; all levels
+//                              in one merged launch (k_polyexp_multi)
 //   k_update_mat    HBM        68  (R0 20 + R1 gather 20 + flow 8 -> M 20); also forms the level's
 //                              initial flow (x2 upsample: 2 in at quarter res + 8 out) in the same pass
-//   k_blur_solve    HBM        28  (M 20 -> flow 8) [+68 when the next UpdateMatrices is fused]
+//   k_blur_solve    HBM        28  (M 20 -> flow 8) [+68 when the next UpdateMatrices is fused; on large
+//                              levels the first iteration also runs the level's flow init + UpdateMatrices_0]
 #include "ffl_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
