@@ -8,6 +8,14 @@ pass 1 (|div| argmax + mean magnitude), the +-6 centre smoothing on the host and
 weighted mean).  Batches are software-pipelined (batch s+1 is queued before batch s is finalised)
 so the device never waits for the host.
 
+After the timed region the results of the timed steps are compared with golden scalars the CPU oracle
+produced in the build container (tests/golden/bench_*.json: argmax index + value bit-exact, reductions to
+1e-4, three flow fields by crc32) -> "checked"; then, on rank 0 at N = 1, three short extra passes add
+  "kernel_classes"   HIP events around every kernel class (per-class ms, algorithmic bytes, roofline fraction)
+  "pcie_inclusive"   host numpy frames (gray and BGR) -> scalars, uploads included (never `value`)
+  "small_image"      the reference's own operating point, 256x256 pairs in large batches (FF:1057)
+and "cpu_baseline" times the C oracle on the host cores.
+
 N > 1: one process per GPU (torchrun), every rank streams its own clip (weak scaling, pairs are
 independent); the only exchange is the barrier/MAX around the timed region and a host (gloo) gather
 of the per-pair scalars -- no RCCL collective in the data path.
@@ -16,6 +24,7 @@ Prints ONE JSON line on rank 0.
 """
 import argparse
 import gc
+import hashlib
 import json
 import os
 import sys
@@ -26,10 +35,22 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-DOMINANT = "k_blur_solve"  # per profiles/*_kernel_stats.csv; --profile-all re-derives it live
-
+DOMINANT = "k_blur_solve"  # per profiles/*_kernel_stats.csv; the "kernel_classes" pass re-derives it live
+PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s measured copy ceiling)
 
 FUSE_FIRST = 10000  # the library's default threshold; --fuse-first overrides (see ffl_set_option)
+
+
+def kernel_signature():
+    """sha256 over the device sources: profiles/traffic.json records the signature it was measured on, and a
+    PMC traffic figure is only reported for the kernels it was measured on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "funscript_flow_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def alg_bytes_per_batch(N, B, U, level_sizes):
@@ -42,7 +63,7 @@ def alg_bytes_per_batch(N, B, U, level_sizes):
     3 x (M 20 -> flow 8) + 2 x 68 = 220 n_k.  On the levels where the library folds the flow-init and
     UpdateMatrices_0 stages into the first blur+solve launch (ffl_set_option "fuse_first": levels with at least
     that many 64x16 tiles over the batch; their M and flow never reach memory) those stages' bytes are counted on
-    the k_blur_solve class; `roofline.traffic` is the measured traffic."""
+    the k_blur_solve class; `roofline.traffic` is the measured traffic and `roofline.frac_measured` its rate."""
     s = float(sum(lw * lh for lw, lh in level_sizes))
     um = ks = 0.0
     for k, (lw, lh) in enumerate(level_sizes):
@@ -65,8 +86,8 @@ def alg_bytes_per_batch(N, B, U, level_sizes):
 
 
 def cpu_baseline(frames, threads, pairs):
-    """Oracle (C restatement, 'port') timed on the host cores: one pair per thread, like the
-    reference's Pool(threads).starmap over pairs (FunscriptFlow.pyw:1190-1191)."""
+    """Oracle (C restatement, 'port') timed on the host cores: one pair per worker, like the
+    reference's Pool(os.cpu_count()).starmap over pairs (FunscriptFlow.pyw:1190-1191)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from concurrent.futures import ThreadPoolExecutor
     import oracle as orc
@@ -84,6 +105,113 @@ def cpu_baseline(frames, threads, pairs):
     return pairs / dt, dt
 
 
+class StepRunner:
+    """B-pair steps over U resident gray frames: enqueue / finalize with DEPTH batches queued ahead."""
+    DEPTH = 2
+
+    def __init__(self, ctx, B, independent, smooth_radius):
+        self.ctx, self.B = ctx, B
+        if independent:
+            self.f0, self.f1 = [2 * i for i in range(B)], [2 * i + 1 for i in range(B)]
+        else:
+            self.f0, self.f1 = list(range(B)), list(range(1, B + 1))
+        jj = np.arange(B)
+        self.lo, self.hi = np.maximum(0, jj - smooth_radius), np.minimum(B, jj + smooth_radius + 1)
+        self.results, self.trace = [], []
+
+    def enqueue(self, step):
+        slots = [(step % (self.DEPTH + 1)) * self.B + i for i in range(self.B)]
+        self.ctx.flow_pairs(self.f0, self.f1, slots)
+        return slots
+
+    def finalize(self, slots):
+        B = self.B
+        recs = self.ctx.pass1_results(slots, 7.0)                  # one call per batch
+        psum = np.zeros((B + 1, 2), np.int64)                      # FF:1203-1214 inside the batch: exact integer
+        psum[1:] = np.cumsum(np.array([(r[0], r[1]) for r in recs], np.int64), axis=0)   # window sums / counts
+        cs = (psum[self.hi] - psum[self.lo]) / (self.hi - self.lo)[:, None]
+        dots = self.ctx.radial(slots, cs, [r[4] for r in recs], False)
+        self.results.append((recs, dots, slots))
+
+    def run(self, steps, trace=False):
+        pending = []
+        for s in range(steps):
+            if trace:
+                self.trace.append(time.perf_counter())
+            pending.append(self.enqueue(s))
+            if len(pending) > self.DEPTH:
+                self.finalize(pending.pop(0))
+        while pending:
+            self.finalize(pending.pop(0))
+        self.ctx.sync()
+
+
+def resident_pass(W, H, B, steps, warmup, device, seed, events, independent=False, zoom=0.0, barrier=None, trace=False):
+    """The timed region of the contract on a fresh context: returns (dt, prof, runner, frames, level_sizes, U)."""
+    from funscript_flow_amd import _capi
+    from funscript_flow_amd.pipeline import SMOOTH_RADIUS
+    from funscript_flow_amd.synth import sine_translate_frames
+    U = 2 * B if independent else B + 1
+    frames = sine_translate_frames(U, W, H, seed=seed, zoom=zoom)
+    ctx = _capi.Context(W, H, device=device, frame_slots=U + 1, flow_slots=3 * B, max_batch=B)
+    level_sizes = [ctx.level_size(k) for k in range(ctx.num_levels() + 1)]
+    ctx.upload_frames(0, list(frames))
+    ctx.sync()
+    runner = StepRunner(ctx, B, independent, SMOOTH_RADIUS)
+    if warmup > 0:
+        runner.run(warmup)
+    runner.results.clear()
+    ctx.profile_enable(events)
+    # A generation-2 collection walks every object torch's import created (40-50 ms: longer than the whole
+    # timed region at small frame sizes); park those objects in the permanent generation first.
+    gc.collect()
+    gc.freeze()
+    if barrier:
+        barrier()
+    t0 = time.perf_counter()
+    runner.run(steps, trace)
+    if barrier:
+        barrier()
+    dt = time.perf_counter() - t0
+    prof = ctx.profile_read()
+    ctx.profile_enable(False)
+    return dt, prof, runner, frames, level_sizes, U, ctx
+
+
+def verify(runner, frames, W, H, B, seed, ctx):
+    """Timed steps vs the oracle goldens: every step must give the same records and scalars (same inputs), the
+    last one is compared number by number, its flow slots are still resident for the crc check."""
+    from funscript_flow_amd import golden_check
+    gold = golden_check.load_golden(W, H, B, seed)
+    if gold is None or not runner.results:
+        return None, "no golden file for this workload (oracle/gen_bench_golden.py W H B seed)"
+    recs, dots, slots = runner.results[-1]
+    for r2, d2, _ in runner.results[:-1]:
+        if [tuple(r) for r in r2] != [tuple(r) for r in recs] or list(d2) != list(dots):
+            return False, "two timed steps over the same frames gave different results"
+    return golden_check.check_batch(gold, frames, recs, dots, lambda j: ctx.download_flow(slots[j]))
+
+
+def pcie_inclusive(W, H, B, device, seed, n_frames, bgr):
+    """Host numpy frames -> per-pair scalars through pipeline.PairEngine: every frame crosses PCIe once (pinned
+    staging copy + hipMemcpyAsync on the copy stream, overlapped with the previous batches' kernels)."""
+    from funscript_flow_amd import _capi, pipeline
+    from funscript_flow_amd.synth import gray_to_bgr, sine_translate_frames
+    base = sine_translate_frames(17, W, H, seed=seed)
+    if bgr:
+        base = gray_to_bgr(base)
+    frames = [base[i % 17] for i in range(n_frames)]
+    with _capi.Context(W, H, device=device, max_batch=B, frame_slots=2 * B + 2, flow_slots=pipeline.min_flow_slots(B)) as ctx:
+        eng = pipeline.PairEngine(ctx)
+        eng.process_chunk(frames[:2 * B + 1])  # warm-up
+        t0 = time.perf_counter()
+        eng.process_chunk(frames)
+        dt = time.perf_counter() - t0
+    n = n_frames - 1
+    return {"value": n / dt, "unit": "pairs/s", "pairs": n, "input": "BGR uint8 ndarrays" if bgr else "gray uint8 ndarrays",
+            "h2d_GBps": n / dt * W * H * (3 if bgr else 1) / 1e9, "pairs_per_batch": B}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -95,7 +223,8 @@ def main():
                     help="pairs per ffl_flow_pairs call (a step); 32 fills the device at every pyramid level: "
                          "1080p 4450 / 4700 / 5030 / 4880 pairs/s at B = 8 / 16 / 32 / 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the kernel_classes / pcie_inclusive / small_image passes")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread, >= 32)")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
     ap.add_argument("--zoom", type=float, default=0.0,
                     help="breathing zoom of the synthetic clip (0 = BASELINE's pure sine-translate); a zooming clip has a "
@@ -105,18 +234,17 @@ def main():
                          "launch (library default 10000; 0: never, 1: always)")
     ap.add_argument("--blur-rows", type=int, default=0, help="tiles a k_blur_solve workgroup walks down (0 = automatic)")
     ap.add_argument("--trace-steps", action="store_true", help="print per-step host wall times to stderr")
-    ap.add_argument("--blur-tile-h", type=int, default=0, help="k_blur_solve LDS tile rows (fixed at 16)")
     ap.add_argument("--lanes", type=int, default=0, help="compute lanes (co-scheduled batches) per context, default 1")
     ap.add_argument("--expand", type=int, default=0, choices=[0, 1, 2],
                     help="schedule of the frame-only kernels (pyramid + PolyExp): 0 (default) serial on the lane's "
                          "stream; 2 the 4 levels fork onto side streams and join before the flow chain starts; "
-                         "1 run-ahead, the chain waits per level (coarse-level flow launches get co-scheduled and "
-                         "stretched: +3 %% pairs/s)")
+                         "1 run-ahead, the chain waits per level")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the process group is gloo")
     ap.add_argument("--no-events", action="store_true", help="diagnostic: no per-kernel HIP events (roofline omitted)")
     ap.add_argument("--profile-all", action="store_true",
-                    help="HIP events around every kernel class (adds ~0.2 ms/step); default: the dominant kernel only")
+                    help="HIP events around every kernel class in the TIMED region (adds ~0.2 ms/step); default: the "
+                         "dominant kernel only, the other classes are timed in the separate kernel_classes pass")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -145,8 +273,6 @@ def main():
             host_group = dist.new_group(backend="gloo")
 
     from funscript_flow_amd import _capi
-    from funscript_flow_amd.pipeline import SMOOTH_RADIUS
-    from funscript_flow_amd.synth import sine_translate_frames
 
     global FUSE_FIRST
     if args.fuse_first >= 0:
@@ -154,62 +280,14 @@ def main():
         FUSE_FIRST = args.fuse_first
     if args.blur_rows:
         _capi.set_option("blur_rows", args.blur_rows)
-    if args.blur_tile_h:
-        _capi.set_option("blur_tile_h", args.blur_tile_h)
     # One compute lane by default: kernels of consecutive batches then run back to back, so the
     # per-launch HIP-event durations behind `roofline` are those of the kernel alone (and agree with
-    # rocprofv3's).  `--lanes 2` (the library's default for production use) co-schedules two batches:
-    # ~+11 % pairs/s at 1080p, but every launch is stretched by its co-runner (profiles/README.md).
+    # rocprofv3's).  `--lanes 2` (the library's default for production use) co-schedules two batches.
     _capi.set_option("lanes", args.lanes or 1)
     _capi.set_option("run_ahead", args.expand)
     W, H, B = args.width, args.height, args.batch
     N = W * H
-    U = 2 * B if args.independent else B + 1
-    frames = sine_translate_frames(U, W, H, seed=1 if world == 1 else 10 + rank, zoom=args.zoom)
-    ctx = _capi.Context(W, H, device=local_rank, frame_slots=U + 1, flow_slots=3 * B, max_batch=B)
-    level_sizes = [ctx.level_size(k) for k in range(ctx.num_levels() + 1)]
-    for i in range(U):
-        ctx.upload_frame(i, frames[i])
-    ctx.sync()
-    if args.independent:
-        f0, f1 = [2 * i for i in range(B)], [2 * i + 1 for i in range(B)]
-    else:
-        f0, f1 = list(range(B)), list(range(1, B + 1))
-
-    results = []
-
-    DEPTH = 2  # batches queued ahead of the one being finalised (flow slots: (DEPTH + 1) * B)
-    jj = np.arange(B)
-    lo, hi = np.maximum(0, jj - SMOOTH_RADIUS), np.minimum(B, jj + SMOOTH_RADIUS + 1)
-
-    def enqueue(step):
-        slots = [(step % (DEPTH + 1)) * B + i for i in range(B)]
-        ctx.flow_pairs(f0, f1, slots)
-        return slots
-
-    def finalize(slots):
-        recs = ctx.pass1_results(slots, 7.0)                       # one call per batch
-        psum = np.zeros((B + 1, 2), np.int64)                      # FF:1203-1214 inside the batch: exact integer
-        psum[1:] = np.cumsum(np.array([(r[0], r[1]) for r in recs], np.int64), axis=0)   # window sums / counts
-        cs = (psum[hi] - psum[lo]) / (hi - lo)[:, None]
-        dots = ctx.radial(slots, cs, [r[4] for r in recs], False)
-        results.append((recs, dots))
-
-    TRACE, TRACE2 = [], []
-
-    def run(steps):
-        pending = []
-        for s in range(steps):
-            if args.trace_steps:
-                TRACE.append(time.perf_counter())
-            pending.append(enqueue(s))
-            if args.trace_steps:
-                TRACE2.append(time.perf_counter())
-            if len(pending) > DEPTH:
-                finalize(pending.pop(0))
-        while pending:
-            finalize(pending.pop(0))
-        ctx.sync()
+    seed = 1 if world == 1 else 10 + rank
 
     def barrier():
         torch.cuda.synchronize()
@@ -217,37 +295,32 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if args.warmup > 0:
-        run(args.warmup)
-    results.clear()
-    ctx.profile_enable(False if args.no_events else (True if args.profile_all else [DOMINANT]))
-    # A generation-2 collection walks every object torch's import created (40-50 ms: longer than the whole
-    # timed region at small frame sizes); park those objects in the permanent generation first.
-    gc.collect()
-    gc.freeze()
-    barrier()
-    t0 = time.perf_counter()
-    run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if TRACE:
-        d = np.diff(np.array(TRACE[-args.steps:])) * 1e3
+    events = False if args.no_events else (True if args.profile_all else [DOMINANT])
+    dt, prof, runner, frames, level_sizes, U, ctx = resident_pass(
+        W, H, B, args.steps, args.warmup, local_rank, seed, events, args.independent, args.zoom, barrier, args.trace_steps)
+    if runner.trace:
+        d = np.diff(np.array(runner.trace[-args.steps:])) * 1e3
         print("step ms:", " ".join(f"{v:.2f}" for v in d), file=sys.stderr)
-        e = (np.array(TRACE2[-args.steps:]) - np.array(TRACE[-args.steps:])) * 1e3
-        print("enqueue ms:", " ".join(f"{v:.2f}" for v in e), file=sys.stderr)
-    prof = ctx.profile_read()
-    ctx.profile_enable(False)
+    plain = not args.independent and args.zoom == 0.0
+    checked, check_detail = verify(runner, frames, W, H, B, seed, ctx) if plain else (None, "non-default clip")
+    results = runner.results
+    ctx.close()
 
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
         # host gather of the per-pair scalars (x, y, cut, dot): the path's only exchange, ~40 B/pair
-        mine = np.array([[r[0], r[1], int(r[4]), d] for recs, dots in results for r, d in zip(recs, dots)], np.float64)
+        mine = np.array([[r[0], r[1], int(r[4]), d] for recs, dots, _ in results for r, d in zip(recs, dots)], np.float64)
         gathered = [None] * world if rank == 0 else None
         dist.gather_object(mine, gathered, dst=0, group=host_group)
+        flags = [None] * world if rank == 0 else None
+        dist.gather_object((checked, check_detail), flags, dst=0, group=host_group)
         if rank == 0:
             assert sum(len(g) for g in gathered) == world * args.steps * B
+            bad = [f for f in flags if f[0] is False]
+            checked = False if bad else (True if all(f[0] is True for f in flags) else None)
+            check_detail = bad[0][1] if bad else f"{sum(f[0] is True for f in flags)} of {world} ranks have goldens for their clip; " + flags[0][1]
 
     if rank == 0:
         pairs = world * args.steps * B
@@ -255,15 +328,25 @@ def main():
         dom = max((k for k in alg), key=lambda k: prof[k][1])
         n_launch, ms = prof[dom]
         achieved = alg[dom] * args.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        traffic = None
+        avg_ms = ms / max(n_launch, 1)
+        traffic, traffic_note = None, "profiles/traffic.json absent"
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("workload") == f"{W}x{H}" and tj.get("batch") == B and tj.get("kernel") == dom:
+                if tj.get("workload") != f"{W}x{H}" or tj.get("batch") != B or tj.get("kernel") != dom:
+                    traffic_note = "profiles/traffic.json was measured on another workload"
+                elif tj.get("kernel_signature") != kernel_signature():
+                    traffic_note = (f"profiles/traffic.json is stale: measured on kernels {tj.get('kernel_signature')}, "
+                                    f"this build is {kernel_signature()} (re-run profiles/tools/capture_round.sh)")
+                elif tj.get("fuse_first", 10000) != FUSE_FIRST:
+                    traffic_note = "profiles/traffic.json was measured with another fuse_first"
+                else:
                     traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+                    traffic_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernels "
+                                    f"{tj.get('kernel_signature')} ({tj.get('captured', '?')}); 2 x FETCH + WRITE, KiB")
+            except Exception as e:  # noqa: BLE001
+                traffic_note = f"profiles/traffic.json unreadable: {e}"
         out = {
             "metric": "1080p frame-pairs/sec" if (W, H) == (1920, 1080) else f"{W}x{H} frame-pairs/sec",
             "value": pairs / dt,
@@ -277,26 +360,66 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
+            "checked": checked,
+            "check_detail": check_detail,
             "config": {"workload": f"{W}x{H} synthetic sine-translate frame-pair stream, gray frames resident in HBM",
                        "pairs_per_step": B, "frames_per_step": U, "levels": len(level_sizes), "winsize": 15, "iterations": 3,
-                       "poly_n": 5, "parallelism": f"pair-shard x{world}", "compute_lanes": args.lanes or 1},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic,
-                         "launches": n_launch, "avg_launch_ms": ms / max(n_launch, 1),
+                       "poly_n": 5, "parallelism": f"pair-shard x{world}", "compute_lanes": args.lanes or 1,
+                       "kernel_signature": kernel_signature()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / PEAK_GBPS, "traffic": traffic,
+                         "frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_GBPS) if traffic and avg_ms > 0 else None,
+                         "traffic_note": traffic_note,
+                         "launches": n_launch, "avg_launch_ms": avg_ms,
                          "alg_bytes_per_launch": alg[dom] * args.steps / max(n_launch, 1)},
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
             "whole_path": {"alg_bytes_per_pair": sum(alg.values()) / B,
                            "achieved_GBps": sum(alg.values()) / B * (pairs / world) / dt / 1e9},
         }
+        if world == 1 and not args.no_extras:
+            # (1) every kernel class under HIP events, in a pass of its own (the events cost ~0.2 ms per step)
+            ksteps = max(3, min(args.steps, 6))
+            kdt, kprof, _, _, _, _, kctx = resident_pass(W, H, B, ksteps, 1, local_rank, seed, True, args.independent, args.zoom)
+            kctx.close()
+            out["kernel_classes"] = {
+                k: {"ms_per_step": v[1] / ksteps, "launches_per_step": v[0] / ksteps,
+                    "alg_bytes_per_step": alg.get(k), "frac": (alg[k] / (v[1] / ksteps * 1e-3) / 1e9 / PEAK_GBPS) if k in alg and v[1] > 0 else None}
+                for k, v in kprof.items() if v[0]}
+            out["kernel_classes"]["_pass"] = {"steps": ksteps, "ms_per_step_with_events": kdt / ksteps * 1e3}
+            # (2) PCIe-inclusive: host frames -> scalars (never `value`)
+            _capi.set_option("lanes", 2)
+            nfr = 8 * B + 1
+            out["pcie_inclusive"] = {"gray": pcie_inclusive(W, H, B, local_rank, seed, nfr, False),
+                                     "bgr": pcie_inclusive(W, H, B, local_rank, seed, nfr, True),
+                                     "note": "pipeline.PairEngine, 2 compute lanes, pageable ndarrays copied into pinned staging"}
+            _capi.set_option("lanes", args.lanes or 1)
+            # (3) the reference's own operating point (FF:1057: every frame is resized to 256x256 first)
+            if (W, H) != (256, 256):
+                SB = min(_capi.FFL_MAX_BATCH, 256)
+                sdt, sprof, srun, sfr, slv, sU, sctx = resident_pass(256, 256, SB, 30, 5, local_rank, 1, [DOMINANT])
+                schk = verify(srun, sfr, 256, 256, SB, 1, sctx)
+                sctx.close()
+                salg = alg_bytes_per_batch(256 * 256, SB, sU, slv)
+                out["small_image"] = {"workload": "256x256 pairs (FF:1057), gray frames resident", "pairs_per_step": SB,
+                                      "value": 30 * SB / sdt, "unit": "pairs/s", "ms_per_step": sdt / 30 * 1e3,
+                                      "whole_path_GBps": sum(salg.values()) * 30 / sdt / 1e9,
+                                      "whole_path_frac": sum(salg.values()) * 30 / sdt / 1e9 / PEAK_GBPS,
+                                      "checked": schk[0], "check_detail": schk[1]}
         if world == 1 and not args.no_cpu_baseline:
-            threads = min(os.cpu_count() or 1, 16)
-            npairs = args.cpu_pairs or 2 * threads   # ~20 s of CPU work at 1080p (0.6 s per pair and core)
+            cores = os.cpu_count() or 1
+            threads = cores                              # the reference: Pool(os.cpu_count()) over pairs, FF:1190
+            npairs = args.cpu_pairs or max(threads, 32)  # one pair per worker: ~0.6 s per 1080p pair and core
             v, cdt = cpu_baseline(frames, threads, npairs)
-            out["cpu_baseline"] = {"value": v, "unit": "pairs/s", "cores": threads, "kind": "port",
-                                   "sample": f"{npairs} pairs of the same {W}x{H} stream, one pair per thread, "
+            try:
+                usable = len(os.sched_getaffinity(0))
+            except AttributeError:
+                usable = cores
+            out["cpu_baseline"] = {"value": v, "unit": "pairs/s", "cores": cores, "threads": threads, "usable_cores": usable,
+                                   "kind": "port",
+                                   "sample": f"{npairs} pairs of the same {W}x{H} stream, one pair per worker thread, "
+                                             f"{threads} threads = os.cpu_count() as the reference's Pool (FF:1190), "
                                              f"C oracle (Farneback + argmax + mean + radial), {cdt:.1f} s wall"}
         print(json.dumps(out))
-    ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -123,7 +124,13 @@ struct ffl_ctx {
     int prof_launches[FFL_K_COUNT] = {0};
     double prof_ms[FFL_K_COUNT] = {0};
     std::string err;
+    // Every entry point takes this lock, so calls from several host threads are safe; the calls that wait for the
+    // device (ffl_pass1_result, ffl_download_flow) drop it while they wait, so a thread collecting results does
+    // not hold up another one that is uploading frames or queueing the next batch (submit / pass1 /
+    // radial on distinct slots may come from different host threads).
+    std::recursive_mutex mu;
 };
+typedef std::unique_lock<std::recursive_mutex> CtxLock;
 
 static int set_err(ffl_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
@@ -371,8 +378,11 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
                ffl_ctx **out) {
     if (!out) return set_err(nullptr, FFL_ERR_INVALID, "ffl_create: out is NULL");
     *out = nullptr;
-    if (width < 16 || height < 16 || (long)width * height > (1L << 31) - 1)
-        return set_err(nullptr, FFL_ERR_INVALID, "ffl_create: unsupported frame size %dx%d", width, height);
+    // upper bound: the kernels index a pair's 5 M planes (20 bytes per pixel) and a batch's pixels with 32-bit
+    // offsets -> 20 * w * h must stay below 2^32 (about 214 Mpx; 5760x2880 is 16.6 Mpx)
+    if (width < 16 || height < 16 || (long)width * height * 20 >= (1L << 32))
+        return set_err(nullptr, FFL_ERR_INVALID, "ffl_create: unsupported frame size %dx%d (16x16 .. 20*w*h < 2^32)", width,
+                       height);
     if (n_frame_slots < 2 || n_flow_slots < 1 || max_batch < 1 || max_batch > FFL_MAX_BATCH)
         return set_err(nullptr, FFL_ERR_INVALID, "ffl_create: bad slot/batch counts (%d, %d, %d)", n_frame_slots,
                        n_flow_slots, max_batch);
@@ -479,6 +489,7 @@ static bool in_host_buf(const ffl_ctx *c, const uint8_t *p, size_t bytes) {
 
 int ffl_host_alloc(ffl_ctx *c, size_t bytes, void **out) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     if (!out || bytes == 0) return set_err(c, FFL_ERR_INVALID, "ffl_host_alloc: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     uint8_t *p = nullptr;
@@ -490,6 +501,7 @@ int ffl_host_alloc(ffl_ctx *c, size_t bytes, void **out) {
 
 int ffl_host_free(ffl_ctx *c, void *ptr) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     for (size_t i = 0; i < c->host_bufs.size(); i++)
         if (c->host_bufs[i].first == ptr) {
             HIPCHK(c, hipStreamSynchronize(c->s_copy));  // no transfer may still be reading it
@@ -506,6 +518,7 @@ int ffl_host_free(ffl_ctx *c, void *ptr) {
 int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames, int width, int height, int channels,
                       ptrdiff_t stride_bytes) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     if (!frames || n < 1 || first < 0 || first + n > c->n_fslots)
         return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames: bad frame slot range %d..%d", first, first + n - 1);
     if (width != c->w || height != c->h)
@@ -546,7 +559,12 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
         uint8_t *bgr = c->d_bgr + (size_t)first * N * 3;
         HIPCHK(c, hipMemcpyAsync(bgr, src0, N * 3 * n, hipMemcpyHostToDevice, c->s_copy));
         ProfScope ps(c, FFL_K_GRAY, c->s_copy);
-        ffl_launch_gray(bgr, gray, (int)(N * n), c->s_copy);
+        // k_gray counts pixels in 32 bits: runs of frames of at most 2^30 pixels per launch
+        const int per = (int)((size_t)(1u << 30) / N) > 0 ? (int)((size_t)(1u << 30) / N) : 1;
+        for (int i = 0; i < n; i += per) {
+            const int m = n - i < per ? n - i : per;
+            ffl_launch_gray(bgr + (size_t)i * N * 3, gray + (size_t)i * N, (int)(N * m), c->s_copy);
+        }
     }
     hipEvent_t ev = c->up_ring[c->up_next++ % (2 * FFL_EV_RING)];
     HIPCHK(c, hipEventRecord(ev, c->s_copy));
@@ -563,6 +581,7 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
 int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *frames, int sw, int sh,
                           ptrdiff_t stride_bytes, int rgb_order, int rw, int rh, int crop_x, int crop_y) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     if (!frames || n < 1 || first < 0 || first + n > c->n_fslots)
         return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames_raw: bad frame slot range %d..%d", first, first + n - 1);
     if (sw < 1 || sh < 1 || sw > 32768 || sh > 32768 || rw < 1 || rh < 1 || rw > 32768 || rh > 32768)
@@ -637,6 +656,7 @@ int ffl_upload_frame(ffl_ctx *c, int fslot, const uint8_t *data, int width, int 
 
 int ffl_download_frame(ffl_ctx *c, int fslot, uint8_t *dst) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     if (!dst || fslot < 0 || fslot >= c->n_fslots)
         return set_err(c, FFL_ERR_INVALID, "ffl_download_frame: bad frame slot %d", fslot);
     if (!c->frame_valid[fslot]) return set_err(c, FFL_ERR_STATE, "ffl_download_frame: frame slot %d was never uploaded", fslot);
@@ -785,7 +805,7 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         if (!fuse_first) {
             ProfScope ps(c, FFL_K_UPDATE_MATRICES, st);
             // the x2 upsample of the coarser level's flow (K3) is fused into this launch
-            ffl_launch_update_matrices(Rk, R_stride, plane, pt, n, L.d_M[mi], M_stride, lw, lh, pw, ph, pw == 0, st);
+            ffl_launch_update_matrices(Rk, R_stride, plane, pt, n, L.d_M[mi], M_stride, lw, lh, pw, ph, pw == 0, cap != nullptr, st);
         }
         bool captured = false;
         auto capture = [&]() -> int {
@@ -811,7 +831,7 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
                     ffl_launch_blur_solve_first(L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, n, lw, lh, pw, ph, st);
                 else
                     ffl_launch_blur_solve(L.d_M[mi], L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, n, lw, lh,
-                                          update, st);
+                                          update, cap != nullptr, st);
             }
             if (update) mi ^= 1;
         }
@@ -865,6 +885,7 @@ static int check_pairs(ffl_ctx *c, int n, const int *f0, const int *f1, const in
 
 int ffl_flow_pairs(ffl_ctx *c, int n, const int *fslot0, const int *fslot1, const int *flow_slots, int pov_mode) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     int rc = check_pairs(c, n, fslot0, fslot1, flow_slots);
     if (rc) return rc;
     HIPCHK(c, hipSetDevice(c->device));
@@ -875,6 +896,7 @@ int ffl_flow_pairs(ffl_ctx *c, int n, const int *fslot0, const int *fslot1, cons
 int ffl_debug_pair(ffl_ctx *c, int f0, int f1, int level, int iter, float *I0, float *I1, float *R0, float *R1,
                    float *M, float *flow) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     int slot = 0;
     int rc = check_pairs(c, 1, &f0, &f1, &slot);
     if (rc) return rc;
@@ -890,10 +912,19 @@ int ffl_debug_pair(ffl_ctx *c, int f0, int f1, int level, int iter, float *I0, f
 int ffl_pass1_result(ffl_ctx *c, int slot, float cut_threshold, int32_t *x, int32_t *y, float *div_val, float *mean_mag,
                      int *cut) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     if (slot < 0 || slot >= c->n_slots) return set_err(c, FFL_ERR_INVALID, "flow slot %d out of range", slot);
     if (!c->slot_state[slot]) return set_err(c, FFL_ERR_STATE, "flow slot %d holds no result", slot);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventSynchronize(c->ev_slot_done[slot]));
+    {
+        // wait without the lock: the event handle is a ring entry that is only ever re-recorded for LATER work
+        // of the same lane, so waiting on it after another thread queued more batches is still sufficient
+        hipEvent_t ev = c->ev_slot_done[slot];
+        lk.unlock();
+        hipError_t e = hipEventSynchronize(ev);
+        lk.lock();
+        HIPCHK(c, e);
+    }
     const Pass1Result &r = c->h_res[slot];
     float mm = (float)(r.mag_sum / ((double)c->w * (double)c->h));
     if (x) *x = r.x;
@@ -907,7 +938,10 @@ int ffl_pass1_result(ffl_ctx *c, int slot, float cut_threshold, int32_t *x, int3
 int ffl_pass1_results(ffl_ctx *c, int n, const int *slots, float cut_threshold, int32_t *x, int32_t *y, float *div_val,
                       float *mean_mag, int *cut) {
     if (!c) return FFL_ERR_INVALID;
-    if (n < 0 || (n > 0 && !slots)) return set_err(c, FFL_ERR_INVALID, "ffl_pass1_results: bad arguments");
+    if (n < 0 || (n > 0 && !slots)) {
+        CtxLock lk(c->mu);
+        return set_err(c, FFL_ERR_INVALID, "ffl_pass1_results: bad arguments");
+    }
     for (int i = 0; i < n; i++) {
         int rc = ffl_pass1_result(c, slots[i], cut_threshold, x ? x + i : nullptr, y ? y + i : nullptr,
                                   div_val ? div_val + i : nullptr, mean_mag ? mean_mag + i : nullptr,
@@ -920,6 +954,7 @@ int ffl_pass1_results(ffl_ctx *c, int n, const int *slots, float cut_threshold, 
 int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const double *cy, const int *is_cut, int pov_mode,
                double *out) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     if (n < 1 || n > FFL_MAXB || !slots || !cx || !cy || !out) return set_err(c, FFL_ERR_INVALID, "ffl_radial: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     RadialTab rt;
@@ -953,16 +988,24 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
 
 int ffl_download_flow(ffl_ctx *c, int slot, float *dst) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     if (slot < 0 || slot >= c->n_slots || !dst) return set_err(c, FFL_ERR_INVALID, "ffl_download_flow: bad arguments");
     if (!c->slot_state[slot]) return set_err(c, FFL_ERR_STATE, "flow slot %d holds no flow", slot);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipEventSynchronize(c->ev_slot_done[slot]));
+    {
+        hipEvent_t ev = c->ev_slot_done[slot];
+        lk.unlock();
+        hipError_t e = hipEventSynchronize(ev);
+        lk.lock();
+        HIPCHK(c, e);
+    }
     HIPCHK(c, hipMemcpy(dst, c->d_flow + (size_t)slot * 2 * c->N, sizeof(float) * 2 * c->N, hipMemcpyDeviceToHost));
     return FFL_OK;
 }
 
 int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     if (slot < 0 || slot >= c->n_slots || !src) return set_err(c, FFL_ERR_INVALID, "ffl_upload_flow: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->s_post;
@@ -990,6 +1033,7 @@ int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
 int ffl_submit_pair(ffl_ctx *c, int slot, const uint8_t *prev, const uint8_t *next, int width, int height, int channels,
                     ptrdiff_t stride_bytes, int pov_mode) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     if (slot < 0 || 2 * slot + 1 >= c->n_fslots || slot >= c->n_slots)
         return set_err(c, FFL_ERR_INVALID, "ffl_submit_pair: slot %d needs frame slots %d,%d and a flow slot", slot, 2 * slot, 2 * slot + 1);
     int rc = ffl_upload_frame(c, 2 * slot, prev, width, height, channels, stride_bytes);
@@ -1002,6 +1046,7 @@ int ffl_submit_pair(ffl_ctx *c, int slot, const uint8_t *prev, const uint8_t *ne
 
 int ffl_sync(ffl_ctx *c) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     HIPCHK(c, hipStreamSynchronize(c->s_copy));
     for (auto &L : c->lanes) HIPCHK(c, hipStreamSynchronize(L.st));
@@ -1043,6 +1088,7 @@ int ffl_set_option(const char *name, int value) {
 
 int ffl_profile_enable(ffl_ctx *c, unsigned class_mask) {
     if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     ffl_sync(c);
     prof_collect(c);
     c->prof_mask = class_mask;

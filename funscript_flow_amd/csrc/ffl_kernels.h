@@ -94,12 +94,16 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut,
                           GaussKernel gk, float *tmp, size_t tmp_stride, float *I, size_t I_stride, hipStream_t st);
 void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stride, size_t plane, int nU, int lw,
                         int lh, PolyConsts pc, hipStream_t st);
-// pw > 0: also produce the level's initial flow = x2 bilinear upsample of pt.prev (pw x ph) into pt.flow;
+// pw > 0: the level's initial flow = x2 bilinear upsample of pt.prev (pw x ph), used from registers (and written
+// to pt.flow only when store_flow != 0: nothing but the debug capture reads it);
 // pw == 0: the flow is read from pt.flow, or taken as zero without touching memory when zero_flow != 0
 void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
-                                size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, hipStream_t st);
+                                size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, int store_flow,
+                                hipStream_t st);
+// update != 0: the next UpdateMatrices is fused in; the solved flow then only reaches memory when store_flow != 0
+// (it is dead until the level's last iteration, which always stores it)
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
-                           size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st);
+                           size_t plane, PairTab pt, int nB, int lw, int lh, int update, int store_flow, hipStream_t st);
 
 
 void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane, PairTab pt,

@@ -796,7 +796,7 @@ void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stri
 template <int MODE>
 __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R, size_t R_stride, size_t plane,
                                                          PairTab pt, float *__restrict__ M, size_t M_stride, int w,
-                                                         int h, int pw, int ph, double usx, double usy) {
+                                                         int h, int pw, int ph, double usx, double usy, int store_flow) {
     int b, tile_x, tile_y;
     if (!ffl_tile_coord((w + 63) / 64, (h + 15) / 16, b, tile_x, tile_y)) return;
     // two adjacent pixels per lane (8-byte R0 / M / 16-byte flow accesses): 32 lanes span the 64-wide
@@ -847,7 +847,9 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
                 t1 = p10.y * a0 + p11.y * a1;
                 f1.y = (t0 * b0 + t1 * b1) * 2.0f;
             }
-            if (in) {
+            // the upsampled field is consumed right here; nothing downstream reads it (k_blur_solve overwrites the
+            // flow without reading it), so it only goes to memory for the debug capture
+            if (in && store_flow) {
                 if (second) {
                     ffl_f4u t;
                     t.x = f0.x; t.y = f0.y; t.z = f1.x; t.w = f1.y;
@@ -872,17 +874,18 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
 }
 
 void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
-                                size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, hipStream_t st) {
+                                size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, int store_flow,
+                                hipStream_t st) {
     dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + 15) / 16, nB));
     if (pw > 0)
         hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
-                           pw, ph, (double)pw / lw, (double)ph / lh);
+                           pw, ph, (double)pw / lw, (double)ph / lh, store_flow);
     else if (zero_flow)
         hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh, 0, 0,
-                           1.0, 1.0);
+                           1.0, 1.0, 0);
     else
         hipLaunchKernelGGL(k_update_matrices<0>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh, 0, 0,
-                           1.0, 1.0);
+                           1.0, 1.0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -974,7 +977,7 @@ void ffl_set_blur_rows(int n) { g_blur_rows = n; }
 template <bool UPDATE, int FIRST>
 __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) void k_blur_solve(
     const float *__restrict__ Min, float *__restrict__ Mout, size_t M_stride, const float *__restrict__ R, size_t R_stride,
-    size_t plane, PairTab pt, int w, int h, int nrb, int pw, int ph, double usx, double usy) {
+    size_t plane, PairTab pt, int w, int h, int nrb, int pw, int ph, double usx, double usy, int store_flow) {
     constexpr int TW = 64, TH = 16, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
     constexpr int PX = 4;  // consecutive pixels per lane in phase H
     constexpr int NCARRY = LH - TH;  // rows of a tile's 30 that the tile below needs again
@@ -1193,7 +1196,10 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
                 const float4 ff = sF4[(ly * FP + lx) >> 1];
                 const float2 f0 = make_float2(ff.x, ff.y), f1 = make_float2(ff.z, ff.w);
                 const size_t o = (size_t)y * w + x;
-                if (in) {
+                // UPDATE launches: the displacement is consumed by the fused UpdateMatrices below and the next
+                // iteration reads only M -- the field itself is dead until the level's last iteration (8 B per
+                // pixel and launch not written; the debug capture asks for it)
+                if (in && (!UPDATE || store_flow)) {
                     if (second) {
                         ffl_f4u t;
                         t.x = ff.x; t.y = ff.y; t.z = ff.z; t.w = ff.w;
@@ -1219,16 +1225,16 @@ static int ffl_blur_rows_per_wg(int tiles_x, int tiles_y, int nB) {
 }
 
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
-                           size_t plane, PairTab pt, int nB, int lw, int lh, int update, hipStream_t st) {
+                           size_t plane, PairTab pt, int nB, int lw, int lh, int update, int store_flow, hipStream_t st) {
     const int tiles_x = (lw + 63) / 64, tiles_y = (lh + 15) / 16;
     const int nrb = g_blur_rows > 0 ? g_blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB);
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (update)
         hipLaunchKernelGGL((k_blur_solve<true, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
-                           lh, nrb, 0, 0, 1.0, 1.0);
+                           lh, nrb, 0, 0, 1.0, 1.0, store_flow);
     else
         hipLaunchKernelGGL((k_blur_solve<false, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt,
-                           lw, lh, nrb, 0, 0, 1.0, 1.0);
+                           lw, lh, nrb, 0, 0, 1.0, 1.0, 1);
 }
 
 // first iteration of a level with the initial UpdateMatrices folded in (pw > 0: initial flow = x2 upsample of
@@ -1240,8 +1246,8 @@ void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, s
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (pw > 0)
         hipLaunchKernelGGL((k_blur_solve<true, 1>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
-                           R_stride, plane, pt, lw, lh, nrb, pw, ph, (double)pw / lw, (double)ph / lh);
+                           R_stride, plane, pt, lw, lh, nrb, pw, ph, (double)pw / lw, (double)ph / lh, 0);
     else
         hipLaunchKernelGGL((k_blur_solve<true, 2>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
-                           R_stride, plane, pt, lw, lh, nrb, 0, 0, 1.0, 1.0);
+                           R_stride, plane, pt, lw, lh, nrb, 0, 0, 1.0, 1.0, 0);
 }

@@ -7,8 +7,9 @@ process_video (FunscriptFlow.pyw:1187-1242) for the "HIP" backend.
     pass 2  radial_motion_weighted(flow_j, c_j, cut_j, pov_mode)            FF:1232-1236
 
 Everything runs in the calling process (HIP state must not cross fork); flows never leave HBM.
-Multi-GPU: pairs are sharded in contiguous blocks; the only exchange is a host all-gather of the
-16-byte pass-1 records (no RCCL collective).
+Multi-GPU: pairs are sharded over the ranks either in contiguous blocks or round-robin in blocks of
+`block` pairs (`shard_pairs`); the only exchange is a host all-gather of the 16-byte pass-1 records (no
+RCCL collective).
 """
 import numpy as np
 
@@ -31,11 +32,35 @@ def smooth_centers(pos_centers, radius=SMOOTH_RADIUS):
     return out
 
 
+def min_flow_slots(max_batch):
+    """Flow slots a streaming two-pass schedule needs (the bound include/ffl.h documents for ffl_create)."""
+    return 2 * max_batch + 2 * SMOOTH_RADIUS + 1
+
+
 def shard_range(n_items, world, rank):
     """Contiguous block [lo, hi) of rank `rank`; block sizes differ by at most one."""
     base, rem = divmod(n_items, world)
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_pairs(n_items, world, rank, assign="contiguous", block=1):
+    """Sorted pair indices owned by `rank`.
+
+    "contiguous"   one block per rank (shard_range): consecutive pairs share a frame, so a rank uploads and
+                   expands ~1 frame per pair, and the +-6 window of FF:1203-1214 stays local except at the two
+                   block edges.  Needs the number of pairs up front.
+    "round_robin"  blocks of `block` consecutive pairs dealt to ranks in turn (block k -> rank k % world):
+                   BASELINE's "frame-pairs sharded round-robin" (block = 1), usable on a stream whose length is
+                   not known when the first pairs are dispatched.  A rank expands (block + 1) / block frames
+                   per pair (2 at block = 1, where no two of its pairs share a frame)."""
+    if assign == "contiguous":
+        lo, hi = shard_range(n_items, world, rank)
+        return np.arange(lo, hi)
+    if assign != "round_robin" or block < 1:
+        raise ValueError(f"unknown pair assignment {assign!r} / block {block}")
+    idx = np.arange(n_items)
+    return idx[(idx // block) % world == rank]
 
 
 class PairEngine:
@@ -52,48 +77,77 @@ class PairEngine:
         self.ctx = ctx
         self.upload = upload or ctx.upload_frames
         self.B = ctx.max_batch
-        if ctx.frame_slots < 2 * self.B + 2 or ctx.flow_slots < 3 * self.B + 2 * SMOOTH_RADIUS + 1:
-            raise ValueError("context too small: need frame_slots >= 2B+2 and flow_slots >= 3B+13")
+        # frame slots: a batch's <= B+1 (stream) / 2B (arbitrary pairs) frames + the next batch's new ones;
+        # flow slots: two batches in flight + the <= 6 pairs still waiting for their +-6 window (2B + 6 live
+        # at most; 2B + 13 is the bound ffl.h documents and Context defaults to)
+        if ctx.frame_slots < 2 * self.B + 2 or ctx.flow_slots < min_flow_slots(self.B):
+            raise ValueError(f"context too small: need frame_slots >= 2B+2 = {2 * self.B + 2} and "
+                             f"flow_slots >= 2B+13 = {min_flow_slots(self.B)}")
 
     def pass1(self, frames, pair_lo, pair_hi, pov_mode=False, cut_threshold=7.0, on_batch=None):
         """Run pass 1 for pairs [pair_lo, pair_hi) of `frames`; flows stay resident in slot
         (j - pair_lo) % flow_slots.  Returns the list of (x, y, val, mean_mag, cut)."""
-        ctx, B = self.ctx, self.B
-        recs = [None] * (pair_hi - pair_lo)
-        uploaded = {}
+        fs = self.ctx.flow_slots
+        return self.pass1_pairs(frames, range(pair_lo, pair_hi), lambda l: l % fs, pov_mode, cut_threshold,
+                                on_batch=(lambda ls, js, got: on_batch(js, got)) if on_batch else None)
 
-        def fslot(i):
-            return i % ctx.frame_slots
+    def pass1_pairs(self, frames, pairs, slot_of, pov_mode=False, cut_threshold=7.0, on_batch=None):
+        """Pass 1 for an arbitrary ascending list of pair indices (pair j = frames[j], frames[j+1]) in batches of
+        max_batch; the flow of the l-th listed pair stays resident in flow slot slot_of(l).  Frames go to the
+        device once per run of batches that needs them: a ring over the frame slots, frames of the batch being
+        assembled are never evicted, and runs of consecutive frames landing in consecutive slots go up with one
+        H2D transfer.  (The library orders an upload into a recycled slot behind the batches that still read
+        it.)  on_batch(local_indices, pair_indices, records) is called per finished batch."""
+        ctx, B, S = self.ctx, self.B, self.ctx.frame_slots
+        pairs = [int(j) for j in pairs]
+        recs = [None] * len(pairs)
+        resident, owner, state = {}, [None] * S, {"next": 0}
 
-        def enqueue(k):
-            js = list(range(k, min(k + B, pair_hi)))
-            new = [i for i in range(js[0], js[-1] + 2) if uploaded.get(fslot(i)) != i]
-            while new:  # runs of consecutive frame slots go up with one H2D transfer each
-                run = [new[0]]
-                while len(run) < len(new) and new[len(run)] == run[-1] + 1 and fslot(new[len(run)]) == fslot(run[-1]) + 1:
-                    run.append(new[len(run)])
-                self.upload(fslot(run[0]), [frames[i] for i in run])
-                for i in run:
-                    uploaded[fslot(i)] = i
-                new = new[len(run):]
-            ctx.flow_pairs([fslot(j) for j in js], [fslot(j + 1) for j in js],
-                           [(j - pair_lo) % ctx.flow_slots for j in js], pov_mode)
-            return js
+        def stage(ids):
+            pinned = {resident[i] for i in ids if i in resident}
+            placed = []
+            for i in ids:
+                if i in resident:
+                    continue
+                while state["next"] % S in pinned:
+                    state["next"] += 1
+                s = state["next"] % S
+                state["next"] += 1
+                if owner[s] is not None:
+                    del resident[owner[s]]
+                owner[s], resident[i] = i, s
+                pinned.add(s)
+                placed.append((i, s))
+            k = 0
+            while k < len(placed):  # runs of consecutive frames in consecutive slots: one transfer each
+                n = 1
+                while (k + n < len(placed) and placed[k + n][0] == placed[k + n - 1][0] + 1
+                       and placed[k + n][1] == placed[k + n - 1][1] + 1):
+                    n += 1
+                self.upload(placed[k][1], [frames[i] for i, _ in placed[k:k + n]])
+                k += n
 
-        def collect(js):
-            got = ctx.pass1_results([(j - pair_lo) % ctx.flow_slots for j in js], cut_threshold)  # one call per batch
-            recs[js[0] - pair_lo:js[-1] + 1 - pair_lo] = got
+        def enqueue(l0):
+            ls = list(range(l0, min(l0 + B, len(pairs))))
+            js = [pairs[l] for l in ls]
+            stage(sorted({j for j in js} | {j + 1 for j in js}))
+            ctx.flow_pairs([resident[j] for j in js], [resident[j + 1] for j in js], [slot_of(l) for l in ls], pov_mode)
+            return ls, js
+
+        def collect(ls, js):
+            got = ctx.pass1_results([slot_of(l) for l in ls], cut_threshold)  # one call per batch
+            recs[ls[0]:ls[-1] + 1] = got
             if on_batch:
-                on_batch(js, got)
+                on_batch(ls, js, got)
 
         pending = None
-        for k in range(pair_lo, pair_hi, B):
-            js = enqueue(k)
+        for l0 in range(0, len(pairs), B):
+            cur = enqueue(l0)
             if pending:
-                collect(pending)
-            pending = js
+                collect(*pending)
+            pending = cur
         if pending:
-            collect(pending)
+            collect(*pending)
         return recs
 
     def process_chunk(self, frames, pov_mode=False, cut_threshold=7.0):
@@ -152,42 +206,82 @@ def frames_to_actions(engine, frames, fps, params):
     return postchain.actions_from_scalars(dots, cuts, frame_idx, fps, params)
 
 
-def process_chunk_sharded(engine, frames, rank, world, allgather, pov_mode=False, cut_threshold=7.0):
-    """Multi-GPU form of one chunk: rank r owns the contiguous pair block shard_range(n, world, r).
+def _shard_pass1(engine, frames, mine, pov_mode, cut_threshold):
+    recs = engine.pass1(frames, mine, pov_mode, cut_threshold) if len(mine) else []
+    return np.array([[j, r[0], r[1], int(r[4])] for j, r in zip(mine, recs)], np.int64).reshape(-1, 4)
 
-    `engine` provides pass1(frames, lo, hi, pov_mode, cut_threshold) -> records and
-    radial(local_indices, centers, cuts, pov_mode) -> floats on its own device; `allgather(obj)`
-    returns the list of every rank's object (a host gather of ~16 B per pair -- the only exchange).
-    Returns the full dots array on every rank."""
+
+def _merge_records(parts, n):
+    """every rank's (pair index, x, y, cut) rows -> (n, 3) array in pair order"""
+    rows = np.concatenate([np.asarray(a, np.int64).reshape(-1, 4) for a in parts], axis=0)
+    assert len(rows) == n and np.array_equal(np.sort(rows[:, 0]), np.arange(n)), "pairs lost or duplicated in the shard"
+    allrecs = np.empty((n, 3), np.int64)
+    allrecs[rows[:, 0]] = rows[:, 1:]
+    return allrecs
+
+
+def _shard_pass2(engine, mine, centers, allrecs, pov_mode):
+    if not len(mine):
+        return np.zeros((0, 2))
+    local = engine.radial(list(range(len(mine))), centers[mine], allrecs[mine, 2].astype(bool), pov_mode)
+    return np.stack([np.asarray(mine, np.float64), np.asarray(local, np.float64)], axis=1)
+
+
+def _merge_dots(parts, n):
+    rows = np.concatenate([np.asarray(p, np.float64).reshape(-1, 2) for p in parts], axis=0)
+    dots = np.empty(n, np.float64)
+    dots[rows[:, 0].astype(np.int64)] = rows[:, 1]
+    return dots
+
+
+def process_chunk_sharded(engine, frames, rank, world, allgather, pov_mode=False, cut_threshold=7.0,
+                          assign="contiguous", block=1):
+    """Multi-GPU form of one chunk: rank r owns the pairs shard_pairs(n, world, r, assign, block).
+
+    `engine` provides pass1(frames, pair_indices, pov_mode, cut_threshold) -> records (its l-th listed pair is
+    local index l) and radial(local_indices, centers, cuts, pov_mode) -> floats on its own device;
+    `allgather(obj)` returns the list of every rank's object (a host gather of ~32 B per pair: pair index, x, y,
+    cut -- the only exchange).  Centres are smoothed over the WHOLE chunk (FF:1203-1214 needs pairs j+-6, which
+    cross shard edges under either assignment).  Returns the full dots array and the (n, 3) records on every rank."""
     n = len(frames) - 1
-    lo, hi = shard_range(n, world, rank)
-    recs = engine.pass1(frames, lo, hi, pov_mode, cut_threshold) if hi > lo else []
-    mine = np.array([[r[0], r[1], int(r[4])] for r in recs], np.int64).reshape(-1, 3)
-    allrecs = np.concatenate([np.asarray(a, np.int64).reshape(-1, 3) for a in allgather(mine)], axis=0)
-    assert len(allrecs) == n
+    mine = shard_pairs(n, world, rank, assign, block)
+    allrecs = _merge_records(allgather(_shard_pass1(engine, frames, mine, pov_mode, cut_threshold)), n)
     centers = smooth_centers(allrecs[:, :2])
-    local = engine.radial(list(range(hi - lo)), centers[lo:hi], allrecs[lo:hi, 2].astype(bool), pov_mode) if hi > lo else []
-    parts = allgather(np.asarray(local, np.float64))
-    return np.concatenate([np.asarray(p, np.float64).reshape(-1) for p in parts]), allrecs
+    return _merge_dots(allgather(_shard_pass2(engine, mine, centers, allrecs, pov_mode)), n), allrecs
+
+
+def process_chunk_local_ranks(engines, frames, pov_mode=False, cut_threshold=7.0, assign="contiguous", block=1):
+    """The same schedule with every rank driven from THIS process (one engine / context per device, or several
+    contexts on one device): phase by phase, no process group.  Equivalent to world = len(engines) processes
+    running process_chunk_sharded."""
+    n, world = len(frames) - 1, len(engines)
+    mine = [shard_pairs(n, world, r, assign, block) for r in range(world)]
+    allrecs = _merge_records([_shard_pass1(e, frames, m, pov_mode, cut_threshold) for e, m in zip(engines, mine)], n)
+    centers = smooth_centers(allrecs[:, :2])
+    return _merge_dots([_shard_pass2(e, m, centers, allrecs, pov_mode) for e, m in zip(engines, mine)], n), allrecs
 
 
 class HipShardEngine:
-    """engine for process_chunk_sharded on one device: keeps the shard's flows resident."""
+    """engine for process_chunk_sharded on one device: keeps the shard's flows resident (local pair l in flow
+    slot l), so the context needs flow_slots >= the shard's pair count and frame_slots >= 2B + 2."""
 
     def __init__(self, ctx, upload=None):
         self.ctx = ctx
-        self.inner = PairEngine.__new__(PairEngine)  # without PairEngine's slot-count check: a shard is bounded below
-        self.inner.ctx, self.inner.B, self.inner.upload = ctx, ctx.max_batch, upload or ctx.upload_frames
+        B = ctx.max_batch
+        if ctx.frame_slots < 2 * B + 2:
+            # two frames of one batch in the same slot would silently compute the wrong flow
+            raise ValueError(f"context too small for a shard engine: need frame_slots >= 2B+2 = {2 * B + 2}")
+        self.inner = PairEngine.__new__(PairEngine)  # a shard's flow slots are bounded by its size, checked in pass1
+        self.inner.ctx, self.inner.B, self.inner.upload = ctx, B, upload or ctx.upload_frames
 
-    def pass1(self, frames, lo, hi, pov_mode, cut_threshold):
-        if hi - lo > self.ctx.flow_slots:
-            raise ValueError("shard does not fit the context's flow slots")
-        return self.inner.pass1(frames, lo, hi, pov_mode, cut_threshold)
+    def pass1(self, frames, pair_indices, pov_mode, cut_threshold):
+        if len(pair_indices) > self.ctx.flow_slots:
+            raise ValueError(f"shard of {len(pair_indices)} pairs does not fit the context's {self.ctx.flow_slots} flow slots")
+        return self.inner.pass1_pairs(frames, pair_indices, lambda l: l, pov_mode, cut_threshold)
 
     def radial(self, local_indices, centers, cuts, pov_mode):
         out, B = [], self.ctx.max_batch
         for s in range(0, len(local_indices), B):
             sl = slice(s, s + B)
-            out += self.ctx.radial([i % self.ctx.flow_slots for i in local_indices[sl]], list(centers[sl]),
-                                   list(cuts[sl]), pov_mode)
+            out += self.ctx.radial(list(local_indices[sl]), list(centers[sl]), list(cuts[sl]), pov_mode)
         return out

@@ -25,8 +25,12 @@
  *   ffl_download_flow       the "flow" entry of that dict (tests / callers that want the array)
  *   ffl_submit_pair         precompute_wrapper((p0, p1), params)                    FF:1019-1021
  *
- * Threading: a context is bound to one device and is internally stream-ordered; calls on one
- * context must be serialised by the caller (one host thread per GPU is the intended use).
+ * Threading: a context is bound to one device and is internally stream-ordered.  Every entry point locks the
+ * context, so calls may come from several host threads (an uploader, a submitter and a result collector working
+ * on distinct slots); the calls that wait for the device (ffl_pass1_result(s), ffl_download_flow)
+ * release the lock while they wait.  ffl_last_error() returns the message of the context's most recent failing
+ * call by any thread.  ffl_set_option() is process-wide and not synchronised: set options before creating
+ * contexts.  Sizes: 16x16 <= width x height, 20 * width * height < 2^32 (32-bit plane offsets in the kernels).
  */
 #ifndef FFL_H
 #define FFL_H
@@ -53,8 +57,8 @@ int ffl_device_count(void);
 
 /* Create a context for frames of exactly width x height on `device`.
  *   n_frame_slots  gray frames resident on the device (>= 2)
- *   n_flow_slots   finished flow fields kept resident for pass 2 (the +-6 smoothing window of
- *                  FF:1203-1214 needs >= 13 + max_batch in a streaming schedule)
+ *   n_flow_slots   finished flow fields kept resident for pass 2 (a streaming two-pass schedule with two batches
+ *                  in flight and the +-6 smoothing window of FF:1203-1214 needs >= 2 * max_batch + 13)
  *   max_batch      pairs processed per ffl_flow_pairs call (1..FFL_MAX_BATCH) */
 int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_slots, int max_batch,
                ffl_ctx **out);

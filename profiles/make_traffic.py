@@ -4,7 +4,10 @@ PMC passes of the bench command:
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d F -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d W -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
-    python profiles/make_traffic.py F/*/*counter_collection.csv W/*/*counter_collection.csv k_blur_solve 1920x1080 8
+    python profiles/make_traffic.py F/*/*counter_collection.csv W/*/*counter_collection.csv k_blur_solve 1920x1080 32 [tag]
+
+The file records the signature of the device sources it was measured on (bench.kernel_signature()); bench.py
+reports `roofline.traffic` only while that signature matches the sources it runs.
 
 Units and gfx950 correction (MI355X_MICROARCH.md, HBM section, checked with profiles/tools/calib_fetch.hip
 on this pool: 1 GiB read at 4/8/16 B per lane reports FETCH_SIZE = 524,300; 256 MiB written reports
@@ -15,6 +18,8 @@ import csv
 import json
 import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_launch(path, kernel, counter):
@@ -28,12 +33,15 @@ def per_launch(path, kernel, counter):
 
 def main():
     fcsv, wcsv, kernel, workload, batch = sys.argv[1:6]
+    tag = sys.argv[6] if len(sys.argv) > 6 else "?"
+    import bench
     f, nf = per_launch(fcsv, kernel, "FETCH_SIZE")
     w, nw = per_launch(wcsv, kernel, "WRITE_SIZE")
     assert nf == nw and nf > 0, (nf, nw)
     out = {"workload": workload, "batch": int(batch), "kernel": kernel, "launches": nf,
            "fetch_size_kib_per_launch_raw": f / nf, "write_size_kib_per_launch": w / nw,
            "hbm_bytes_per_launch": (2.0 * f / nf + w / nw) * 1024.0,
+           "kernel_signature": bench.kernel_signature(), "fuse_first": bench.FUSE_FIRST, "captured": tag,
            "correction": "FETCH_SIZE x2 on gfx950 (calibrated, profiles/tools/calib_fetch.hip), WRITE_SIZE exact, KiB units"}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
     json.dump(out, open(path, "w"), indent=1)

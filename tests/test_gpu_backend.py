@@ -294,3 +294,72 @@ def test_uploads_out_of_pinned_context_memory():
         ctx.upload_frames(0, [np.array(pin3[i]) for i in range(3)])     # same pixels from pageable memory
         ctx.flow_pairs([0, 1], [1, 2], [0, 1])
         assert np.array_equal(a, ctx.download_flow(1))
+
+
+def test_bgr_upload_with_odd_pixel_count_into_later_slots():
+    """k_gray works on 4-pixel groups with 32-bit loads / stores at bgr + slot*3N and gray + slot*N, which are
+    only byte-aligned when N is odd: odd w*h, slots >= 1, single and batched uploads."""
+    w, h = 67, 45                                     # N = 3015, odd
+    fr = sine_translate_frames(4, w, h, seed=3)
+    bgr = gray_to_bgr(fr, gains=(0.9, 1.0, 0.8))
+    want = [orc.bgr2gray(b) for b in bgr]
+    with _capi.Context(w, h, max_batch=2, frame_slots=6, flow_slots=4) as ctx:
+        ctx.upload_frame(1, bgr[0])
+        ctx.upload_frame(3, bgr[1])
+        ctx.upload_frames(4, [bgr[2], bgr[3]])
+        ctx.sync()
+        assert np.array_equal(ctx.download_frame(1), want[0])
+        assert np.array_equal(ctx.download_frame(3), want[1])
+        assert np.array_equal(ctx.download_frame(4), want[2]) and np.array_equal(ctx.download_frame(5), want[3])
+        ctx.flow_pairs([1, 4], [3, 5], [0, 1])
+        assert np.array_equal(ctx.download_flow(0), orc.farneback(want[0], want[1]))
+        assert np.array_equal(ctx.download_flow(1), orc.farneback(want[2], want[3]))
+
+
+def test_context_calls_from_several_host_threads():
+    """submit / pass1 / radial on distinct slots may come from different host threads.  One thread
+    streams a chunk through PairEngine (uploads, batches, pass 2) on flow slots 0..20 while a second one keeps
+    reading records, radial scalars and the flow of a pair parked in slot 30 of the SAME context; both see exactly
+    what a single-threaded run gives."""
+    import threading
+    w, h, n = 192, 128, 60
+    fr = sine_translate_frames(n + 1, w, h, seed=8, amp=(3.0, 2.0), period=13, zoom=0.02)
+    with _capi.Context(w, h, max_batch=4, frame_slots=12, flow_slots=32) as ctx:
+        want_dots, want_recs = pipeline.PairEngine(ctx).process_chunk(fr)
+        ctx.upload_frames(10, [fr[7], fr[8]])
+        ctx.flow_pairs([10], [11], [30])
+        park = (ctx.pass1_result(30), ctx.radial([30], [(90.5, 60.25)], [False], False)[0], ctx.download_flow(30))
+        assert np.array_equal(park[2], orc.farneback(fr[7], fr[8]))
+        errors, stop = [], threading.Event()
+
+        def reader():
+            try:
+                while not stop.is_set():
+                    got = (ctx.pass1_result(30), ctx.radial([30], [(90.5, 60.25)], [False], False)[0])
+                    if got != park[:2] or not np.array_equal(ctx.download_flow(30), park[2]):
+                        errors.append("parked slot changed")
+                        return
+            except Exception as e:  # noqa: BLE001
+                errors.append(repr(e))
+
+        t = threading.Thread(target=reader)
+        t.start()
+        try:
+            sub = _SubCtx(ctx, frame_slots=10, flow_slots=21)
+            for _ in range(3):
+                dots, recs = pipeline.PairEngine(sub).process_chunk(fr)
+                assert np.array_equal(dots, want_dots) and [tuple(r) for r in recs] == [tuple(r) for r in want_recs]
+        finally:
+            stop.set()
+            t.join()
+        assert not errors, errors
+
+
+class _SubCtx:
+    """a view of a context that advertises fewer slots (so that an engine leaves the others alone)"""
+
+    def __init__(self, ctx, frame_slots, flow_slots):
+        self._c, self.frame_slots, self.flow_slots, self.max_batch = ctx, frame_slots, flow_slots, ctx.max_batch
+
+    def __getattr__(self, k):
+        return getattr(self._c, k)

@@ -1,0 +1,218 @@
+"""GPU parity at the sizes and options BASELINE.json names and bench.py times -- through the C ABI.
+
+  configs[1]  1920x1080, B = 32, library-default options (the folded first iteration on levels 0-1, strip walk of
+              8 tiles, merged frame expansion): the exact path the driver's bench line comes from
+  configs[2]  3840x2160, B = 32
+  configs[3]  8 x 1080p clips over 8 ranks (here: 8 shard engines on the one GPU of the test box)
+  configs[4]  5760x2880 side-by-side stereo, each 2880x2880 eye an independent image (FF:1074-1083)
+
+Oracle runs are bounded to a few pairs per size (1 s at 1080p, 4 s at 4K / 2880^2 per pair and core); everything
+else is checked against goldens made by the oracle in the build container (tests/golden/bench_*.json) and through
+size-independent properties (reductions = the numpy restatement applied to the device's own flow; identical inputs
+at different batch positions give identical bits)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+import oracle as orc
+from funscript_flow_amd import _capi, golden_check, pipeline
+from funscript_flow_amd.synth import sine_translate_frames
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run_bench_batch(ctx, frames, B):
+    """one bench.py step: B pairs of a B+1-frame stream, pass 1, centre smoothing inside the batch, pass 2"""
+    for i in range(B + 1):
+        ctx.upload_frame(i, frames[i])
+    slots = list(range(B))
+    ctx.flow_pairs(list(range(B)), list(range(1, B + 1)), slots)
+    recs = ctx.pass1_results(slots, 7.0)
+    centers = pipeline.smooth_centers([(r[0], r[1]) for r in recs])
+    dots = ctx.radial(slots, centers, [r[4] for r in recs], False)
+    return recs, dots
+
+
+def _check_reductions_on_own_flow(ctx, j, rec, flow):
+    ox, oy, ov = orc.max_divergence_np(flow)
+    assert (rec[0], rec[1]) == (ox, oy) and np.float32(rec[2]).tobytes() == np.float32(ov).tobytes(), j
+    rm = float(orc.mean_mag_np(flow))
+    assert abs(float(rec[3]) - rm) <= 1e-4 * rm, j
+
+
+@pytest.mark.parametrize("lanes", [1, 2])
+def test_shipped_configuration_1080p_b32_against_oracle(lanes):
+    """bench.py's step (B = 32, default fuse_first / blur_rows / merge_expand; lanes = 1 is the bench's setting,
+    2 the library default): all 32 records and scalars against the oracle goldens, three flow fields bit for bit
+    against the oracle run here, the other 29 through their crc or the period-16 property."""
+    W, H, B = 1920, 1080, 32
+    frames = sine_translate_frames(B + 1, W, H, seed=1)
+    gold = golden_check.load_golden(W, H, B, 1)
+    assert gold is not None
+    try:
+        _capi.set_option("lanes", lanes)
+        with _capi.Context(W, H, frame_slots=B + 2, flow_slots=3 * B, max_batch=B) as ctx:
+            recs, dots = _run_bench_batch(ctx, frames, B)
+            flows = {j: ctx.download_flow(j) for j in range(B)}
+    finally:
+        _capi.set_option("lanes", 2)
+    status, detail = golden_check.check_batch(gold, frames, recs, dots, lambda j: flows[j])
+    assert status is not False, detail
+    for j in (0, B // 2 - 1, B - 1):                                   # first, middle, last pair of the batch
+        assert np.array_equal(flows[j], orc.farneback(frames[j], frames[j + 1])), j
+    for j in range(B):
+        _check_reductions_on_own_flow(None, j, recs[j], flows[j])
+    for j in range(B - 16):                                            # frames repeat with period 16
+        assert np.array_equal(flows[j], flows[j + 16]) and tuple(recs[j]) == tuple(recs[j + 16]), j
+
+
+def test_4k_b32_against_oracle():
+    W, H, B = 3840, 2160, 32
+    frames = sine_translate_frames(B + 1, W, H, seed=1)
+    gold = golden_check.load_golden(W, H, B, 1)
+    assert gold is not None
+    try:
+        _capi.set_option("lanes", 1)
+        with _capi.Context(W, H, frame_slots=B + 2, flow_slots=B, max_batch=B) as ctx:
+            recs, dots = _run_bench_batch(ctx, frames, B)
+            status, detail = golden_check.check_batch(gold, frames, recs, dots, ctx.download_flow)
+            assert status is not False, detail
+            f5 = ctx.download_flow(5)
+            assert np.array_equal(f5, orc.farneback(frames[5], frames[6]))      # one pair against the oracle here
+            for j in range(0, B - 16, 3):
+                a, b = ctx.download_flow(j), ctx.download_flow(j + 16)
+                assert np.array_equal(a, b), j
+                _check_reductions_on_own_flow(ctx, j, recs[j], a)
+                assert tuple(recs[j]) == tuple(recs[j + 16])
+    finally:
+        _capi.set_option("lanes", 2)
+
+
+def test_config4_stereo_5760x2880_split_per_eye():
+    """configs[4]: the two 2880x2880 eyes of a 5760x2880 side-by-side frame go to the device straight out of the
+    full frame (row stride 5760, no host copy); left eye bit-exact against the oracle, right eye through the
+    reductions on its own flow; both eyes of both frames in ONE batch of independent pairs."""
+    EW, EH = 2880, 2880
+    full = sine_translate_frames(2, 2 * EW, EH, seed=2)                   # (2, 2880, 5760)
+    with _capi.Context(EW, EH, max_batch=2, frame_slots=4, flow_slots=2) as ctx:
+        for eye in (0, 1):
+            for t in (0, 1):
+                view = full[t][:, eye * EW:(eye + 1) * EW]
+                assert not view.flags["C_CONTIGUOUS"] and view.strides[0] == 2 * EW
+                ctx.upload_frame(2 * eye + t, view)
+        ctx.flow_pairs([0, 2], [1, 3], [0, 1])
+        recs = ctx.pass1_results([0, 1], 7.0)
+        left, right = ctx.download_flow(0), ctx.download_flow(1)
+        ref = orc.farneback(np.ascontiguousarray(full[0][:, :EW]), np.ascontiguousarray(full[1][:, :EW]))
+        assert np.array_equal(left, ref)
+        for j, f in ((0, left), (1, right)):
+            _check_reductions_on_own_flow(ctx, j, recs[j], f)
+            c = (0.45 * EW, 0.52 * EH)
+            got = ctx.radial([j], [c], [False], False)[0]
+            want = float(orc.radial_np(f, c, False, False))
+            assert abs(got - want) <= 1e-4 * max(abs(want), 1e-6 * EW)
+        assert not np.array_equal(left, right)
+        # the same eye through a contiguous copy gives the same bits (the stride path changes nothing)
+        ctx.upload_frame(0, np.ascontiguousarray(full[0][:, EW:]))
+        ctx.upload_frame(1, np.ascontiguousarray(full[1][:, EW:]))
+        ctx.flow_pairs([0], [1], [0])
+        assert np.array_equal(ctx.download_flow(0), right)
+
+
+def test_config3_eight_1080p_clips_over_eight_shard_engines():
+    """configs[3] on one GPU: 8 clips (seeds 10..17, as bench.py --gpus 8 gives its ranks) x 1080p.
+    (a) weak form (one clip per rank, what bench.py times): rank r's HipShardEngine on its own context gives the
+        scalars of a plain PairEngine run of clip r;
+    (b) one clip's pairs dealt over the 8 engines round-robin (BASELINE's wording) and in contiguous blocks: the
+        gathered scalars equal the single-engine run; one pair against the oracle."""
+    W, H, n_pairs, R, B = 1920, 1080, 8, 8, 4
+    clips = [sine_translate_frames(n_pairs + 1, W, H, seed=10 + r, zoom=0.02) for r in range(R)]
+    ctxs = [_capi.Context(W, H, max_batch=B, frame_slots=2 * B + 2, flow_slots=pipeline.min_flow_slots(B)) for _ in range(R)]
+    try:
+        single = []
+        for r in range(R):
+            dots, recs = pipeline.PairEngine(ctxs[r]).process_chunk(clips[r])
+            single.append((dots, np.array([[x[0], x[1], int(x[4])] for x in recs], np.int64)))
+        engines = [pipeline.HipShardEngine(c) for c in ctxs]
+        for r in range(R):                                                # (a) a clip per rank
+            dots, allrecs = pipeline.process_chunk_sharded(engines[r], clips[r], 0, 1, lambda o: [o])
+            assert np.array_equal(dots, single[r][0]) and np.array_equal(allrecs, single[r][1]), r
+        for assign, block in (("round_robin", 1), ("round_robin", 2), ("contiguous", 1)):   # (b) a clip over 8 ranks
+            dots, allrecs = pipeline.process_chunk_local_ranks(engines, clips[3], assign=assign, block=block)
+            assert np.array_equal(dots, single[3][0]) and np.array_equal(allrecs, single[3][1]), (assign, block)
+        # after the contiguous run rank 5 holds pair 5 of clip 3 in its flow slot 0
+        assert np.array_equal(ctxs[5].download_flow(0), orc.farneback(clips[3][5], clips[3][6]))
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+_RANK_WORKER = r"""
+import os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, {root!r})
+from funscript_flow_amd import _capi, pipeline
+from funscript_flow_amd.synth import sine_translate_frames
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+frames = sine_translate_frames(22, 320, 180, seed=4, amp=(3.0, 2.0), period=9, zoom=0.02)
+def allgather(obj):
+    out = [None] * world
+    dist.all_gather_object(out, obj)
+    return out
+res = []
+with _capi.Context(320, 180, device=0, max_batch=4, frame_slots=10, flow_slots=21) as ctx:   # both ranks on cuda:0
+    eng = pipeline.HipShardEngine(ctx)
+    for assign, block in (("contiguous", 1), ("round_robin", 1), ("round_robin", 4)):
+        dots, recs = pipeline.process_chunk_sharded(eng, frames, rank, world, allgather, assign=assign, block=block)
+        res.append(np.concatenate([dots, recs.reshape(-1).astype(np.float64)]))
+if rank == 0:
+    np.save({out!r}, np.stack(res))
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_on_one_device_under_gloo(tmp_path):
+    """The N > 1 path with real devices: two processes (torch.distributed.run, gloo), each with its own context
+    on cuda:0, run process_chunk_sharded under every assignment; the gathered result equals the single-rank run."""
+    out = str(tmp_path / "res.npy")
+    script = tmp_path / "rank_worker.py"
+    script.write_text(_RANK_WORKER.format(root=ROOT, out=out))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29573", str(script)], env=env, timeout=600)
+    got = np.load(out)
+    frames = sine_translate_frames(22, 320, 180, seed=4, amp=(3.0, 2.0), period=9, zoom=0.02)
+    with _capi.Context(320, 180, max_batch=4, frame_slots=10, flow_slots=21) as ctx:
+        dots, recs = pipeline.PairEngine(ctx).process_chunk(frames)
+    want = np.concatenate([dots, np.array([[r[0], r[1], int(r[4])] for r in recs], np.float64).reshape(-1)])
+    for g in got:
+        assert np.array_equal(g, want)
+    j = 13
+    with _capi.Context(320, 180, max_batch=1) as ctx:
+        ctx.submit_pair(0, frames[j], frames[j + 1])
+        assert np.array_equal(ctx.download_flow(0), orc.farneback(frames[j], frames[j + 1]))
+
+
+def test_batches_above_eight_pairs_small_sizes():
+    """Batches of 17 .. 64 pairs at sizes where the oracle covers every pair (no parity test used a batch
+    above 8), with the library's default fold threshold and with thresholds that fold every / some levels."""
+    for (w, h, B, fuse) in [(640, 360, 32, 10000), (640, 360, 32, 1), (256, 256, 64, 10000), (200, 120, 17, 2000)]:
+        frames = sine_translate_frames(B + 1, w, h, seed=1, zoom=0.01)
+        try:
+            _capi.set_option("fuse_first", fuse)
+            with _capi.Context(w, h, frame_slots=B + 2, flow_slots=B, max_batch=B) as ctx:
+                recs, dots = _run_bench_batch(ctx, frames, B)
+                flows = [ctx.download_flow(j) for j in range(B)]
+        finally:
+            _capi.set_option("fuse_first", 10000)
+        for j in range(B):
+            assert np.array_equal(flows[j], orc.farneback(frames[j], frames[j + 1])), (w, h, B, fuse, j)
+            _check_reductions_on_own_flow(None, j, recs[j], flows[j])

@@ -112,9 +112,9 @@ from funscript_flow_amd import pipeline
 from funscript_flow_amd.synth import sine_translate_frames
 
 class OracleEngine:  # the checker standing in for a device: exercises the sharding / exchange logic only
-    def pass1(self, frames, lo, hi, pov_mode, cut_threshold):
+    def pass1(self, frames, pair_indices, pov_mode, cut_threshold):
         self.flows, recs = [], []
-        for j in range(lo, hi):
+        for j in pair_indices:
             flow = orc.farneback(frames[j], frames[j + 1])
             self.flows.append(flow)
             x, y, v = (frames[j].shape[1] // 2, frames[j].shape[0] - 1, 0) if pov_mode else orc.max_divergence_np(flow)
@@ -131,16 +131,20 @@ def allgather(obj):
     out = [None] * world
     dist.all_gather_object(out, obj)
     return out
-dots, recs = pipeline.process_chunk_sharded(OracleEngine(), frames, rank, world, allgather)
+out = []
+for assign, block in (("contiguous", 1), ("round_robin", 1), ("round_robin", 2)):
+    dots, recs = pipeline.process_chunk_sharded(OracleEngine(), frames, rank, world, allgather, assign=assign, block=block)
+    out.append(dots)
 if rank == 0:
-    np.save({out!r}, dots)
+    np.save({out!r}, np.stack(out))
 dist.barrier()
 dist.destroy_process_group()
 """
 
 
 def test_sharded_two_pass_gloo_world2(tmp_path):
-    """N>1 path on CPU: 2 ranks, contiguous pair blocks, host all-gather of pass-1 records only."""
+    """N>1 path on CPU: 2 ranks, contiguous pair blocks and round-robin (blocks of 1 and 2 pairs: BASELINE's
+    "frame-pairs sharded round-robin"), host all-gather of pass-1 records only."""
     out = str(tmp_path / "dots.npy")
     script = tmp_path / "worker.py"
     script.write_text(_WORKER.format(root=ROOT, out=out))
@@ -156,4 +160,69 @@ def test_sharded_two_pass_gloo_world2(tmp_path):
     cuts = [bool(orc.mean_mag_np(f) > 7) for f in flows]
     centers = orc.smooth_centers(pos)
     want = np.array([orc.radial_np(f, c, k) for f, c, k in zip(flows, centers, cuts)])
-    assert np.array_equal(got, want)
+    assert got.shape == (3, 11)
+    for g in got:
+        assert np.array_equal(g, want)
+
+
+def test_shard_pairs_partitions_under_both_assignments():
+    for n in (0, 1, 7, 8, 39):
+        for world in (1, 2, 3, 8):
+            for assign, block in (("contiguous", 1), ("round_robin", 1), ("round_robin", 4)):
+                parts = [pipeline.shard_pairs(n, world, r, assign, block) for r in range(world)]
+                assert sorted(np.concatenate(parts).tolist()) == list(range(n))
+                assert all(np.all(np.diff(p) > 0) for p in parts)
+    assert pipeline.shard_pairs(10, 3, 1, "round_robin", 2).tolist() == [2, 3, 8, 9]
+    with pytest.raises(ValueError):
+        pipeline.shard_pairs(4, 2, 0, "striped")
+
+
+class _FakeCtx:  # records what PairEngine asks of a context; no device
+    def __init__(self, max_batch, frame_slots, flow_slots):
+        self.max_batch, self.frame_slots, self.flow_slots = max_batch, frame_slots, flow_slots
+        self.slots, self.batches, self.uploads = {}, [], []
+
+    def upload_frames(self, first, frames):
+        self.uploads.append((first, len(frames)))
+        for k, f in enumerate(frames):
+            self.slots[first + k] = int(f[0, 0])
+
+    def flow_pairs(self, f0, f1, slots, pov):
+        assert len(set(f0) | set(f1)) == len({self.slots[s] for s in set(f0) | set(f1)}), "two frames of a batch share a slot"
+        self.batches.append([(self.slots[a], self.slots[b], s) for a, b, s in zip(f0, f1, slots)])
+
+    def pass1_results(self, slots, thr):
+        return [(s, 0, np.float32(0), np.float32(0), False) for s in slots]
+
+
+def test_pair_engine_frame_ring_and_slot_bounds():
+    """Host schedule without a device: every batch sees the right frames in distinct slots (streams, arbitrary
+    pair lists, the smallest legal ring), consecutive new frames go up as one run, and the documented slot
+    bounds are the ones PairEngine and Context agree on."""
+    frames = [np.full((2, 2), i, np.uint8) for i in range(40)]
+    for B, S in ((4, 10), (4, 13), (3, 8)):
+        ctx = _FakeCtx(B, S, pipeline.min_flow_slots(B))
+        eng = pipeline.PairEngine(ctx)
+        eng.pass1(frames, 0, 39)
+        got = [p for b in ctx.batches for p in b]
+        assert [(a, b) for a, b, _ in got] == [(j, j + 1) for j in range(39)]
+        assert [s for _, _, s in got] == [j % ctx.flow_slots for j in range(39)]
+        assert sum(n for _, n in ctx.uploads) == 40          # a stream uploads every frame exactly once
+        ctx = _FakeCtx(B, S, 64)
+        eng = pipeline.PairEngine.__new__(pipeline.PairEngine)
+        eng.ctx, eng.B, eng.upload = ctx, B, ctx.upload_frames
+        mine = pipeline.shard_pairs(39, 3, 1, "round_robin", 1)
+        eng.pass1_pairs(frames, mine, lambda l: l)
+        got = [p for b in ctx.batches for p in b]
+        assert [(a, b) for a, b, _ in got] == [(j, j + 1) for j in mine] and [s for _, _, s in got] == list(range(len(mine)))
+    assert pipeline.min_flow_slots(8) == 2 * 8 + 13
+    with pytest.raises(ValueError):
+        pipeline.PairEngine(_FakeCtx(4, 9, 64))               # frame slots < 2B + 2
+    with pytest.raises(ValueError):
+        pipeline.PairEngine(_FakeCtx(4, 10, 20))              # flow slots < 2B + 13
+    with pytest.raises(ValueError):
+        pipeline.HipShardEngine(_FakeCtx(4, 5, 64))           # a batch's frames would alias
+    # the ctypes Context's defaults satisfy PairEngine's check (no device needed to read the formula)
+    import inspect
+    src = inspect.getsource(_capi.Context.__init__)
+    assert "2 * max_batch + 2" in src and "13 + 2 * max_batch" in src
