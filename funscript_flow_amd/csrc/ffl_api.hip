@@ -1073,6 +1073,11 @@ int ffl_set_option(const char *name, int value) {
         ffl_set_blur_rows(value);
         return FFL_OK;
     }
+    if (!strcmp(name, "tile_order")) {  // 0 pair-major, 1 tile-major (ffl_tile_coord)
+        if (value < 0 || value > 1) return FFL_ERR_INVALID;
+        ffl_set_tile_order(value);
+        return FFL_OK;
+    }
     if (!strcmp(name, "lanes")) {  // compute lanes of contexts created afterwards
         if (value < 1 || value > 4) return FFL_ERR_INVALID;
         g_num_lanes = value;

@@ -109,6 +109,7 @@ void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const
 void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane, PairTab pt,
                                  int nB, int lw, int lh, int pw, int ph, hipStream_t st);
 void ffl_set_blur_rows(int n);  // tiles a k_blur_solve workgroup walks down (0 = automatic)
+void ffl_set_tile_order(int order);  // 0 pair-major, 1 tile-major (see ffl_tile_coord)
 
 int ffl_pass1_blocks(int w, int h);
 struct ResTab {  // where each pair's pass-1 record goes
@@ -135,11 +136,24 @@ static inline unsigned ffl_tile_grid(int tiles_x, int tiles_y, int nB) {
     const int T = tiles_x * tiles_y;
     return (unsigned)(((T + 7) / 8) * 8 * nB);
 }
-__device__ __forceinline__ bool ffl_tile_coord(int tiles_x, int tiles_y, int &b, int &tile_x, int &tile_y) {
+// order 0 (pair-major): all tiles of pair 0, then all tiles of pair 1, ...
+// order 1 (tile-major): an XCD walks its run of tiles and runs every tile for ALL nB pairs back to back.  In a
+//   stream, frame j's expansion R is R1 of pair j-1 and R0 of pair j: with the same tile of consecutive pairs
+//   resident on one XCD at the same time, the second of those reads is served by that XCD's L2 instead of the
+//   fabric (the R planes are 40 of the 68 bytes per pixel an UpdateMatrices pass moves).
+__device__ __forceinline__ bool ffl_tile_coord(int tiles_x, int tiles_y, int nB, int order, int &b, int &tile_x,
+                                               int &tile_y) {
     const int T = tiles_x * tiles_y, chunk = (T + 7) >> 3;
-    b = blockIdx.x / (chunk * 8);
-    const int l = blockIdx.x - b * (chunk * 8);
-    const int t = (l & 7) * chunk + (l >> 3);
+    int t;
+    if (order == 0) {
+        b = blockIdx.x / (chunk * 8);
+        const int l = blockIdx.x - b * (chunk * 8);
+        t = (l & 7) * chunk + (l >> 3);
+    } else {
+        const int pos = blockIdx.x >> 3, tt = pos / nB;
+        b = pos - tt * nB;
+        t = (blockIdx.x & 7) * chunk + tt;
+    }
     if (t >= T) return false;
     const int per_panel = FFL_PANEL_W * tiles_y;
     const int panel = t / per_panel, within = t - panel * per_panel;

@@ -796,9 +796,10 @@ void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stri
 template <int MODE>
 __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R, size_t R_stride, size_t plane,
                                                          PairTab pt, float *__restrict__ M, size_t M_stride, int w,
-                                                         int h, int pw, int ph, double usx, double usy, int store_flow) {
+                                                         int h, int pw, int ph, double usx, double usy, int store_flow,
+                                                         int nB, int order) {
     int b, tile_x, tile_y;
-    if (!ffl_tile_coord((w + 63) / 64, (h + 15) / 16, b, tile_x, tile_y)) return;
+    if (!ffl_tile_coord((w + 63) / 64, (h + 15) / 16, nB, order, b, tile_x, tile_y)) return;
     // two adjacent pixels per lane (8-byte R0 / M / 16-byte flow accesses): 32 lanes span the 64-wide
     // tile, a wave covers 2 rows, the workgroup 8 rows per pass, 2 passes
     const int x = tile_x * 64 + 2 * (threadIdx.x & 31);
@@ -873,19 +874,22 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
     }
 }
 
+static int g_tile_order = 0;
+void ffl_set_tile_order(int order) { g_tile_order = order; }
+
 void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
                                 size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, int store_flow,
                                 hipStream_t st) {
     dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + 15) / 16, nB));
     if (pw > 0)
         hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
-                           pw, ph, (double)pw / lw, (double)ph / lh, store_flow);
+                           pw, ph, (double)pw / lw, (double)ph / lh, store_flow, nB, g_tile_order);
     else if (zero_flow)
         hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh, 0, 0,
-                           1.0, 1.0, 0);
+                           1.0, 1.0, 0, nB, g_tile_order);
     else
         hipLaunchKernelGGL(k_update_matrices<0>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh, 0, 0,
-                           1.0, 1.0, 0);
+                           1.0, 1.0, 0, nB, g_tile_order);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -977,7 +981,8 @@ void ffl_set_blur_rows(int n) { g_blur_rows = n; }
 template <bool UPDATE, int FIRST>
 __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) void k_blur_solve(
     const float *__restrict__ Min, float *__restrict__ Mout, size_t M_stride, const float *__restrict__ R, size_t R_stride,
-    size_t plane, PairTab pt, int w, int h, int nrb, int pw, int ph, double usx, double usy, int store_flow) {
+    size_t plane, PairTab pt, int w, int h, int nrb, int pw, int ph, double usx, double usy, int store_flow, int nB,
+    int order) {
     constexpr int TW = 64, TH = 16, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
     constexpr int PX = 4;  // consecutive pixels per lane in phase H
     constexpr int NCARRY = LH - TH;  // rows of a tile's 30 that the tile below needs again
@@ -995,7 +1000,7 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
     // instead of 30 -- its halo re-reads (30 rows for 16 outputs) were the kernel's largest single cost.
     int b, tile_x, strip_y;  // XCD-aware panel order over the strips, see ffl_tile_coord
     const int tiles_y = (h + TH - 1) / TH;
-    if (!ffl_tile_coord((w + TW - 1) / TW, (tiles_y + nrb - 1) / nrb, b, tile_x, strip_y)) return;
+    if (!ffl_tile_coord((w + TW - 1) / TW, (tiles_y + nrb - 1) / nrb, nB, order, b, tile_x, strip_y)) return;
     const int x0 = tile_x * TW;
     const float *Mb = Min + (size_t)b * M_stride;
 
@@ -1231,10 +1236,10 @@ void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (update)
         hipLaunchKernelGGL((k_blur_solve<true, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
-                           lh, nrb, 0, 0, 1.0, 1.0, store_flow);
+                           lh, nrb, 0, 0, 1.0, 1.0, store_flow, nB, g_tile_order);
     else
         hipLaunchKernelGGL((k_blur_solve<false, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt,
-                           lw, lh, nrb, 0, 0, 1.0, 1.0, 1);
+                           lw, lh, nrb, 0, 0, 1.0, 1.0, 1, nB, g_tile_order);
 }
 
 // first iteration of a level with the initial UpdateMatrices folded in (pw > 0: initial flow = x2 upsample of
@@ -1246,8 +1251,8 @@ void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, s
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (pw > 0)
         hipLaunchKernelGGL((k_blur_solve<true, 1>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
-                           R_stride, plane, pt, lw, lh, nrb, pw, ph, (double)pw / lw, (double)ph / lh, 0);
+                           R_stride, plane, pt, lw, lh, nrb, pw, ph, (double)pw / lw, (double)ph / lh, 0, nB, g_tile_order);
     else
         hipLaunchKernelGGL((k_blur_solve<true, 2>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
-                           R_stride, plane, pt, lw, lh, nrb, 0, 0, 1.0, 1.0, 0);
+                           R_stride, plane, pt, lw, lh, nrb, 0, 0, 1.0, 1.0, 0, nB, g_tile_order);
 }
