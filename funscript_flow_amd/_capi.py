@@ -9,7 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libffl_hip.so")
 
 FFL_OK = 0
-FFL_MAX_BATCH = 64
+FFL_MAX_BATCH = 256
 # kernel classes of ffl_profile_read
 KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "k_frontend", "k_update_matrices", "k_blur_solve",
                   "k_pass1", "k_radial"]

@@ -34,6 +34,12 @@ static int g_run_ahead = 0;
 // 2093 vs 1018 + 1217 us; level 2 157 vs 65 + 68 us; level 3 138 vs 34 + 45 us)
 static int g_fuse_first = 10000;
 static int g_merge_expand = 1;  // serial schedule: all levels' pyramid + PolyExp in three merged launches
+// A batch's ~20 launches are captured once per (lane, batch shape, options) into a hipGraph and replayed: the
+// kernels take only pointers and geometry (per-batch indices live in the lane's device table), so nothing in the
+// graph changes from batch to batch.  Host time per batch drops from one launch call per kernel to one graph
+// launch -- what matters at the reference's 256x256 operating point, where a whole batch is a fraction of a ms.
+static int g_use_graph = 1;
+static int g_blur_rows_opt = 0, g_tile_order_opt = 0;  // mirrors of the kernel-side options (part of the graph key)
 
 struct ProfRec {
     int cls;
@@ -74,6 +80,15 @@ struct ffl_ctx {
         float *d_I = nullptr, *d_R = nullptr, *d_M[2] = {nullptr, nullptr}, *d_flowA = nullptr, *d_flowB = nullptr;
         unsigned long long *d_pkey = nullptr;
         double *d_psum = nullptr;
+        // per-batch index tables: device copy + a ring of pinned host copies (entry e belongs to ev_ring[e])
+        BatchTab *d_tab = nullptr, *h_tab = nullptr;
+        bool tab_used[FFL_EV_RING] = {false};
+        struct GraphEntry {
+            int n, nU, pov, fuse_first, blur_rows, tile_order, merge_expand;
+            hipGraph_t graph;
+            hipGraphExec_t exec;
+        };
+        std::vector<GraphEntry> graphs;
     };
     std::vector<Lane> lanes;
     unsigned next_lane = 0;
@@ -108,6 +123,8 @@ struct ffl_ctx {
     std::vector<hipEvent_t> ev_slot_done;
     std::vector<char> slot_state;     // 0 empty, 1 queued/ready
     std::vector<char> slot_pov;
+    RadialTab *d_rtab = nullptr, *h_rtab = nullptr;    // pass-2 table (s_post; ffl_radial waits for the stream, so one copy)
+    BatchTab *d_ptab = nullptr, *h_ptab = nullptr;     // ffl_upload_flow's one-pair table (s_post)
     double *d_rpsum = nullptr;                         // pass-2 partial sums (s_post)
     double *h_radial = nullptr, *d_radial = nullptr;   // pinned pass-2 results and their device alias
     unsigned long long *d_ppkey = nullptr;                                 // ffl_upload_flow scratch (s_post)
@@ -357,6 +374,11 @@ void ffl_destroy(ffl_ctx *c) {
     for (auto &L : c->lanes) {
         hipFree(L.d_I); hipFree(L.d_T); hipFree(L.d_R); hipFree(L.d_M[0]); hipFree(L.d_M[1]);
         hipFree(L.d_flowA); hipFree(L.d_flowB); hipFree(L.d_pkey); hipFree(L.d_psum);
+        hipFree(L.d_tab); hipHostFree(L.h_tab);
+        for (auto &g : L.graphs) {
+            hipGraphExecDestroy(g.exec);
+            hipGraphDestroy(g.graph);
+        }
         for (auto e : L.ev_R)
             if (e) hipEventDestroy(e);
         for (auto e : L.ev_ring)
@@ -369,6 +391,7 @@ void ffl_destroy(ffl_ctx *c) {
     hipFree(c->d_flow);
     hipHostFree(c->h_res);
     hipFree(c->d_rpsum); hipFree(c->d_ppkey); hipHostFree(c->h_radial);
+    hipFree(c->d_rtab); hipHostFree(c->h_rtab); hipFree(c->d_ptab); hipHostFree(c->h_ptab);
     if (c->s_copy) hipStreamDestroy(c->s_copy);
     if (c->s_post) hipStreamDestroy(c->s_post);
     delete c;
@@ -449,13 +472,19 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
         CCHK(hipMalloc(&L.d_M[1], sizeof(float) * 5 * N * max_batch));
         CCHK(hipMalloc(&L.d_flowA, sizeof(float) * 2 * N * max_batch));
         CCHK(hipMalloc(&L.d_flowB, sizeof(float) * 2 * N * max_batch));
-        CCHK(hipMalloc(&L.d_pkey, sizeof(unsigned long long) * c->p1_blocks * FFL_MAXB));
-        CCHK(hipMalloc(&L.d_psum, sizeof(double) * c->p1_blocks * FFL_MAXB));
+        CCHK(hipMalloc(&L.d_pkey, sizeof(unsigned long long) * c->p1_blocks * max_batch));
+        CCHK(hipMalloc(&L.d_psum, sizeof(double) * c->p1_blocks * max_batch));
+        CCHK(hipMalloc(&L.d_tab, sizeof(BatchTab)));
+        CCHK(hipHostMalloc(&L.h_tab, sizeof(BatchTab) * FFL_EV_RING, hipHostMallocDefault));
     }
     CCHK(hipMalloc(&c->d_flow, sizeof(float) * 2 * N * n_flow_slots));
     CCHK(hipHostMalloc(&c->h_res, sizeof(Pass1Result) * n_flow_slots, hipHostMallocMapped));
     CCHK(hipHostGetDevicePointer((void **)&c->d_res, c->h_res, 0));
     CCHK(hipMalloc(&c->d_rpsum, sizeof(double) * c->p1_blocks * FFL_MAXB));
+    CCHK(hipMalloc(&c->d_rtab, sizeof(RadialTab)));
+    CCHK(hipHostMalloc(&c->h_rtab, sizeof(RadialTab), hipHostMallocDefault));
+    CCHK(hipMalloc(&c->d_ptab, sizeof(BatchTab)));
+    CCHK(hipHostMalloc(&c->h_ptab, sizeof(BatchTab), hipHostMallocDefault));
     CCHK(hipMalloc(&c->d_ppkey, sizeof(unsigned long long) * c->p1_blocks));
     CCHK(hipHostMalloc(&c->h_radial, sizeof(double) * FFL_MAXB, hipHostMallocMapped));
     CCHK(hipHostGetDevicePointer((void **)&c->d_radial, c->h_radial, 0));
@@ -671,33 +700,14 @@ struct DebugCapture {
     float *I0, *I1, *R0, *R1, *M, *flow;
 };
 
-// One batch of pairs through the 4-scale Farneback schedule + pass-1 reductions, on compute lane `li`.
-static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, const int *slots, int pov_mode,
-                     const DebugCapture *cap) {
-    ffl_ctx::Lane &L = c->lanes[li];
+// The launches of one batch (frame expansion, the level loop, pass 1) on the lane's stream.  Everything that
+// differs between two batches of the same shape is read by the kernels from the lane's device table, so this
+// sequence can be captured into a hipGraph (cap == nullptr, no timing events, serial schedule).
+static int enqueue_batch(ffl_ctx *c, ffl_ctx::Lane &L, const BatchTab &T, int n, int nU, int pov_mode, const DebugCapture *cap) {
     hipStream_t st = L.st;
     const size_t N = c->N;
-    // unique frames of the batch
-    UTab ut;
-    PairTab pt;
-    memset(&ut, 0, sizeof(ut));
-    memset(&pt, 0, sizeof(pt));
-    int nU = 0;
-    auto uidx = [&](int fs) {
-        for (int i = 0; i < nU; i++)
-            if (ut.fslot[i] == fs) return i;
-        ut.fslot[nU] = fs;
-        return nU++;
-    };
-    for (int i = 0; i < n; i++) {
-        pt.u0[i] = uidx(f0[i]);
-        pt.u1[i] = uidx(f1[i]);
-    }
-    for (int i = 0; i < nU; i++) HIPCHK(c, hipStreamWaitEvent(st, c->ev_uploaded[ut.fslot[i]], 0));
-    // a flow slot being recycled may still be read by the batch (other lane) or pass 2 that used it last
-    for (int i = 0; i < n; i++)
-        if (c->slot_state[slots[i]]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_slot_done[slots[i]], 0));
-
+    const UTab *ut = &L.d_tab->ut;
+    const PairTab *pt = &L.d_tab->pt;
     // frame-only expansion of level k (level image + PolyExp of the nU unique frames) on stream s
     auto expand_level = [&](int k, hipStream_t s) {
         const LevelGeom &g = c->geom[k];
@@ -777,7 +787,6 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         expanded = true;
     }
 
-    float *cur = L.d_flowA, *prv = L.d_flowB;
     int pw = 0, ph = 0;
     for (int k = c->levels; k >= 0; k--) {
         const LevelGeom &g = c->geom[k];
@@ -785,17 +794,10 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         const size_t plane = (size_t)lw * lh;
         const size_t I_stride = plane, R_stride = 5 * plane, M_stride = 5 * plane;
         float *Rk = L.d_R + L.r_off[k];
-        for (int i = 0; i < n; i++) {
-            pt.flow[i] = (k == 0) ? c->d_flow + (size_t)slots[i] * 2 * N : cur + (size_t)i * 2 * plane;
-            pt.prev[i] = prv + (size_t)i * 2 * (size_t)pw * ph;
-        }
         // the coarsest level starts from zero flow; nothing reads that field but UpdateMatrices (which is told
         // so) and the debug capture, so it is only materialised for the latter
-        if (pw == 0 && cap) {
-            if (k > 0) HIPCHK(c, hipMemsetAsync(cur, 0, sizeof(float) * 2 * plane * n, st));
-            else
-                for (int i = 0; i < n; i++) HIPCHK(c, hipMemsetAsync(pt.flow[i], 0, sizeof(float) * 2 * plane, st));
-        }
+        if (pw == 0 && cap)
+            for (int i = 0; i < n; i++) HIPCHK(c, hipMemsetAsync(T.pt.flow[k][i], 0, sizeof(float) * 2 * plane, st));
         if (run_ahead) HIPCHK(c, hipStreamWaitEvent(st, L.ev_R[k], 0));
         else if (!expanded) expand_level(k, st);
         int mi = 0;
@@ -805,17 +807,17 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         if (!fuse_first) {
             ProfScope ps(c, FFL_K_UPDATE_MATRICES, st);
             // the x2 upsample of the coarser level's flow (K3) is fused into this launch
-            ffl_launch_update_matrices(Rk, R_stride, plane, pt, n, L.d_M[mi], M_stride, lw, lh, pw, ph, pw == 0, cap != nullptr, st);
+            ffl_launch_update_matrices(Rk, R_stride, plane, pt, k, n, L.d_M[mi], M_stride, lw, lh, pw, ph, pw == 0, cap != nullptr, st);
         }
         bool captured = false;
         auto capture = [&]() -> int {
             HIPCHK(c, hipStreamSynchronize(st));
-            if (cap->I0) HIPCHK(c, hipMemcpy(cap->I0, L.d_I + L.i_off[k] + (size_t)pt.u0[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
-            if (cap->I1) HIPCHK(c, hipMemcpy(cap->I1, L.d_I + L.i_off[k] + (size_t)pt.u1[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
-            if (cap->R0) HIPCHK(c, hipMemcpy(cap->R0, Rk + (size_t)pt.u0[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
-            if (cap->R1) HIPCHK(c, hipMemcpy(cap->R1, Rk + (size_t)pt.u1[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->I0) HIPCHK(c, hipMemcpy(cap->I0, L.d_I + L.i_off[k] + (size_t)T.pt.u0[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
+            if (cap->I1) HIPCHK(c, hipMemcpy(cap->I1, L.d_I + L.i_off[k] + (size_t)T.pt.u1[0] * I_stride, sizeof(float) * plane, hipMemcpyDeviceToHost));
+            if (cap->R0) HIPCHK(c, hipMemcpy(cap->R0, Rk + (size_t)T.pt.u0[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
+            if (cap->R1) HIPCHK(c, hipMemcpy(cap->R1, Rk + (size_t)T.pt.u1[0] * R_stride, sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
             if (cap->M) HIPCHK(c, hipMemcpy(cap->M, L.d_M[mi], sizeof(float) * 5 * plane, hipMemcpyDeviceToHost));
-            if (cap->flow) HIPCHK(c, hipMemcpy(cap->flow, pt.flow[0], sizeof(float) * 2 * plane, hipMemcpyDeviceToHost));
+            if (cap->flow) HIPCHK(c, hipMemcpy(cap->flow, T.pt.flow[k][0], sizeof(float) * 2 * plane, hipMemcpyDeviceToHost));
             captured = true;
             return FFL_OK;
         };
@@ -828,9 +830,9 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
             {
                 ProfScope ps(c, FFL_K_BLUR_SOLVE, st, it > 0 && !cap);  // the three iterations are queued back to back
                 if (it == 0 && fuse_first)
-                    ffl_launch_blur_solve_first(L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, n, lw, lh, pw, ph, st);
+                    ffl_launch_blur_solve_first(L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, k, n, lw, lh, pw, ph, st);
                 else
-                    ffl_launch_blur_solve(L.d_M[mi], L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, n, lw, lh,
+                    ffl_launch_blur_solve(L.d_M[mi], L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, k, n, lw, lh,
                                           update, cap != nullptr, st);
             }
             if (update) mi ^= 1;
@@ -839,26 +841,85 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
             int rc = capture();
             if (rc) return rc;
         }
-        float *t = cur;
-        cur = prv;
-        prv = t;
         pw = lw;
         ph = lh;
     }
     // pass 1 on the finished level-0 flows; records are stored straight into mapped pinned memory
-    ResTab rtab;
-    memset(&rtab, 0, sizeof(rtab));
-    for (int i = 0; i < n; i++) rtab.r[i] = c->d_res + slots[i];
     {
         ProfScope ps(c, FFL_K_PASS1, st);
-        ffl_launch_pass1(pt, n, c->w, c->h, pov_mode, L.d_pkey, L.d_psum, rtab, st);
+        ffl_launch_pass1(pt, n, c->w, c->h, pov_mode, L.d_pkey, L.d_psum, st);
+    }
+    return FFL_OK;
+}
+
+// One batch of pairs through the 4-scale Farneback schedule + pass-1 reductions, on compute lane `li`.
+static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, const int *slots, int pov_mode,
+                     const DebugCapture *cap) {
+    ffl_ctx::Lane &L = c->lanes[li];
+    hipStream_t st = L.st;
+    const size_t N = c->N;
+    // the batch's table: a pinned ring entry (its previous batch, FFL_EV_RING batches ago, must have consumed it)
+    const unsigned e = L.ring_next % FFL_EV_RING;
+    if (L.tab_used[e]) HIPCHK(c, hipEventSynchronize(L.ev_ring[e]));
+    BatchTab &T = L.h_tab[e];
+    int nU = 0;
+    auto uidx = [&](int fs) {
+        for (int i = 0; i < nU; i++)
+            if (T.ut.fslot[i] == fs) return i;
+        T.ut.fslot[nU] = fs;
+        return nU++;
+    };
+    for (int i = 0; i < n; i++) {
+        T.pt.u0[i] = uidx(f0[i]);
+        T.pt.u1[i] = uidx(f1[i]);
+        T.pt.res[i] = c->d_res + slots[i];
+    }
+    // per level: the pair's flow field -- the lane's two ping-pong buffers, coarsest level in A; level 0 is the slot
+    for (int k = c->levels; k >= 0; k--) {
+        const size_t plane = (size_t)c->geom[k].lw * c->geom[k].lh;
+        float *buf = ((c->levels - k) & 1) ? L.d_flowB : L.d_flowA;
+        for (int i = 0; i < n; i++)
+            T.pt.flow[k][i] = (k == 0) ? c->d_flow + (size_t)slots[i] * 2 * N : buf + (size_t)i * 2 * plane;
+    }
+    for (int k = c->levels + 1; k < FFL_MAX_LEVELS; k++)
+        for (int i = 0; i < n; i++) T.pt.flow[k][i] = nullptr;
+    for (int i = 0; i < nU; i++) HIPCHK(c, hipStreamWaitEvent(st, c->ev_uploaded[T.ut.fslot[i]], 0));
+    // a flow slot being recycled may still be read by the batch (other lane) or pass 2 that used it last
+    for (int i = 0; i < n; i++)
+        if (c->slot_state[slots[i]]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_slot_done[slots[i]], 0));
+    // stream order puts this copy behind the lane's previous batch, which reads the same device table
+    HIPCHK(c, hipMemcpyAsync(L.d_tab, &T, sizeof(BatchTab), hipMemcpyHostToDevice, st));
+    L.tab_used[e] = true;
+
+    const bool use_graph = g_use_graph && !cap && c->prof_mask == 0 && g_run_ahead == 0;
+    if (use_graph) {
+        ffl_ctx::Lane::GraphEntry *ge = nullptr;
+        for (auto &g : L.graphs)
+            if (g.n == n && g.nU == nU && g.pov == pov_mode && g.fuse_first == g_fuse_first && g.blur_rows == g_blur_rows_opt &&
+                g.tile_order == g_tile_order_opt && g.merge_expand == g_merge_expand)
+                ge = &g;
+        if (!ge) {
+            ffl_ctx::Lane::GraphEntry g = {n, nU, pov_mode, g_fuse_first, g_blur_rows_opt, g_tile_order_opt, g_merge_expand, nullptr, nullptr};
+            HIPCHK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = enqueue_batch(c, L, T, n, nU, pov_mode, nullptr);
+            hipError_t ce = hipStreamEndCapture(st, &g.graph);
+            if (rc) return rc;
+            HIPCHK(c, ce);
+            HIPCHK(c, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+            L.graphs.push_back(g);
+            ge = &L.graphs.back();
+        }
+        HIPCHK(c, hipGraphLaunch(ge->exec, st));
+    } else {
+        int rc = enqueue_batch(c, L, T, n, nU, pov_mode, cap);
+        if (rc) return rc;
     }
     // ONE event per batch: it marks the slots' results as ready, the frames' last use and the lane's
     // work buffers as free (a ring, so handles held by older slots only ever point to later work)
     hipEvent_t ev = L.ev_ring[L.ring_next++ % FFL_EV_RING];
     HIPCHK(c, hipEventRecord(ev, st));
     L.ev_done = ev;
-    for (int i = 0; i < nU; i++) c->ev_last_use[(size_t)ut.fslot[i] * c->lanes.size() + li] = ev;
+    for (int i = 0; i < nU; i++) c->ev_last_use[(size_t)T.ut.fslot[i] * c->lanes.size() + li] = ev;
     for (int i = 0; i < n; i++) {
         c->ev_slot_done[slots[i]] = ev;
         c->slot_state[slots[i]] = 1;
@@ -957,8 +1018,7 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
     CtxLock lk(c->mu);
     if (n < 1 || n > FFL_MAXB || !slots || !cx || !cy || !out) return set_err(c, FFL_ERR_INVALID, "ffl_radial: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
-    RadialTab rt;
-    memset(&rt, 0, sizeof(rt));
+    RadialTab &rt = *c->h_rtab;  // the previous call waited for s_post, so the pinned copy is free
     int m = 0;
     int map[FFL_MAXB];
     for (int i = 0; i < n; i++) {
@@ -977,8 +1037,9 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
     if (m == 0) return FFL_OK;
     hipStream_t st = c->s_post;
     {
+        HIPCHK(c, hipMemcpyAsync(c->d_rtab, &rt, sizeof(RadialTab), hipMemcpyHostToDevice, st));
         ProfScope ps(c, FFL_K_RADIAL, st);
-        ffl_launch_radial(rt, m, c->w, c->h, pov_mode, c->d_rpsum, c->d_radial, st);
+        ffl_launch_radial(c->d_rtab, m, c->w, c->h, pov_mode, c->d_rpsum, c->d_radial, st);
     }
     HIPCHK(c, hipStreamSynchronize(st));  // k_radial_final stored into the mapped pinned buffer
     HIPCHK(c, hipGetLastError());
@@ -1012,15 +1073,12 @@ int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
     if (c->slot_state[slot]) HIPCHK(c, hipEventSynchronize(c->ev_slot_done[slot]));
     HIPCHK(c, hipStreamSynchronize(st));
     HIPCHK(c, hipMemcpy(c->d_flow + (size_t)slot * 2 * c->N, src, sizeof(float) * 2 * c->N, hipMemcpyHostToDevice));
-    PairTab pt;
-    memset(&pt, 0, sizeof(pt));
-    pt.flow[0] = c->d_flow + (size_t)slot * 2 * c->N;
-    ResTab rtab;
-    memset(&rtab, 0, sizeof(rtab));
-    rtab.r[0] = c->d_res + slot;
+    c->h_ptab->pt.flow[0][0] = c->d_flow + (size_t)slot * 2 * c->N;  // the stream was drained above: the pinned copy is free
+    c->h_ptab->pt.res[0] = c->d_res + slot;
+    HIPCHK(c, hipMemcpyAsync(c->d_ptab, c->h_ptab, sizeof(BatchTab), hipMemcpyHostToDevice, st));
     {
         ProfScope ps(c, FFL_K_PASS1, st);
-        ffl_launch_pass1(pt, 1, c->w, c->h, pov_mode, c->d_ppkey, c->d_rpsum, rtab, st);
+        ffl_launch_pass1(&c->d_ptab->pt, 1, c->w, c->h, pov_mode, c->d_ppkey, c->d_rpsum, st);
     }
     c->ev_slot_done[slot] = c->post_ring[c->post_next++ % FFL_EV_RING];
     HIPCHK(c, hipEventRecord(c->ev_slot_done[slot], st));
@@ -1071,11 +1129,17 @@ int ffl_set_option(const char *name, int value) {
     if (!strcmp(name, "blur_rows")) {  // tiles a k_blur_solve workgroup walks down: 0 automatic, 1..64
         if (value < 0 || value > 64) return FFL_ERR_INVALID;
         ffl_set_blur_rows(value);
+        g_blur_rows_opt = value;
         return FFL_OK;
     }
     if (!strcmp(name, "tile_order")) {  // 0 pair-major, 1 tile-major (ffl_tile_coord)
         if (value < 0 || value > 1) return FFL_ERR_INVALID;
         ffl_set_tile_order(value);
+        g_tile_order_opt = value;
+        return FFL_OK;
+    }
+    if (!strcmp(name, "graph")) {  // 1 (default): replay a batch's launches from a captured hipGraph, 0: launch eagerly
+        g_use_graph = value != 0;
         return FFL_OK;
     }
     if (!strcmp(name, "lanes")) {  // compute lanes of contexts created afterwards

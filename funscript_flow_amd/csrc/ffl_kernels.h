@@ -12,8 +12,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define FFL_MAXB 64
-#define FFL_MAXU (2 * FFL_MAXB)
+#define FFL_MAXB 256                 // pairs per batch (= FFL_MAX_BATCH of include/ffl.h)
+#define FFL_MAXU (2 * FFL_MAXB)      // unique frames per batch
+#define FFL_MAX_LEVELS 4             // pyramid scales (FarnebackOpticalFlowImpl::calc: levels = 3 -> 4 scales)
 #define FFL_POLY_N 5
 #define FFL_WIN 15
 #define FFL_WIN_R 7
@@ -29,14 +30,25 @@ struct GaussKernel {
     int ksize;
 };
 
+// Per-batch tables live in device memory (one copy per compute lane, refreshed by a small stream-ordered H2D
+// copy before the batch's first launch): a batch may hold hundreds of pairs (the reference's own operating point
+// is 256x256, where only large batches fill the device), far more than fits kernel arguments, and kernels that
+// take only pointers and geometry can be replayed from a captured hipGraph.  Every entry is read with a
+// wave-uniform index (scalar loads).
 struct UTab {  // unique frame u of the batch -> resident frame slot
     int fslot[FFL_MAXU];
 };
 
 struct PairTab {  // per pair of the batch
-    int u0[FFL_MAXB], u1[FFL_MAXB];  // unique-frame indices of prev / next
-    float *flow[FFL_MAXB];           // flow field being refined at the current level
-    const float *prev[FFL_MAXB];     // coarser-level flow (input of the x2 upsample)
+    int u0[FFL_MAXB], u1[FFL_MAXB];          // unique-frame indices of prev / next
+    float *flow[FFL_MAX_LEVELS][FFL_MAXB];   // the pair's flow field at every level (level 0: its flow slot);
+                                             // level k + 1 is the input of level k's x2 upsample
+    struct Pass1Result *res[FFL_MAXB];       // where the pair's pass-1 record goes (mapped pinned memory)
+};
+
+struct BatchTab {
+    UTab ut;
+    PairTab pt;
 };
 
 struct Pass1Result {  // written by k_pass1_final, mirrored to pinned host memory
@@ -84,44 +96,43 @@ struct PolyJobs {
 
 // ---- launchers (each enqueues on `st` and returns; no synchronisation) ----------------------
 // all pyramid levels in two launches; false (nothing launched) when a level needs the generic kernels
-bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, const PyrJob *levels,
+bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, const UTab *ut, int nU, int w, int h, const PyrJob *levels,
                           int n, hipStream_t st);
 void ffl_launch_polyexp_multi(const PolyJob *levels, int n, int nU, PolyConsts pc, hipStream_t st);
 void ffl_launch_frontend(const uint8_t *src, uint8_t *gray, FrontParams p, hipStream_t st);
 void ffl_launch_gray(const uint8_t *bgr, uint8_t *gray, int n_pixels, hipStream_t st);
 size_t ffl_pyr_tmp_floats(int w, int h, int lw);  // per-frame size of the level's horizontal-pass buffer
-void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, int lw, int lh,
+void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, const UTab *ut, int nU, int w, int h, int lw, int lh,
                           GaussKernel gk, float *tmp, size_t tmp_stride, float *I, size_t I_stride, hipStream_t st);
 void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stride, size_t plane, int nU, int lw,
                         int lh, PolyConsts pc, hipStream_t st);
 // pw > 0: the level's initial flow = x2 bilinear upsample of pt.prev (pw x ph), used from registers (and written
 // to pt.flow only when store_flow != 0: nothing but the debug capture reads it);
 // pw == 0: the flow is read from pt.flow, or taken as zero without touching memory when zero_flow != 0
-void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
+void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, const PairTab *pt, int level, int nB, float *M,
                                 size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, int store_flow,
                                 hipStream_t st);
 // update != 0: the next UpdateMatrices is fused in; the solved flow then only reaches memory when store_flow != 0
 // (it is dead until the level's last iteration, which always stores it)
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
-                           size_t plane, PairTab pt, int nB, int lw, int lh, int update, int store_flow, hipStream_t st);
+                           size_t plane, const PairTab *pt, int level, int nB, int lw, int lh, int update, int store_flow,
+                           hipStream_t st);
 
 
-void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane, PairTab pt,
-                                 int nB, int lw, int lh, int pw, int ph, hipStream_t st);
+void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane,
+                                 const PairTab *pt, int level, int nB, int lw, int lh, int pw, int ph, hipStream_t st);
 void ffl_set_blur_rows(int n);  // tiles a k_blur_solve workgroup walks down (0 = automatic)
 void ffl_set_tile_order(int order);  // 0 pair-major, 1 tile-major (see ffl_tile_coord)
 
 int ffl_pass1_blocks(int w, int h);
-struct ResTab {  // where each pair's pass-1 record goes
-    Pass1Result *r[FFL_MAXB];
-};
-void ffl_launch_pass1(PairTab pt, int nB, int w, int h, int pov_mode, unsigned long long *pkey, double *psum,
-                      ResTab results, hipStream_t st);
-struct RadialTab {
+// pass 1 of the level-0 flows pt->flow[0][b]; records go to pt->res[b]
+void ffl_launch_pass1(const PairTab *pt, int nB, int w, int h, int pov_mode, unsigned long long *pkey, double *psum,
+                      hipStream_t st);
+struct RadialTab {  // device-resident like the batch tables
     const float *flow[FFL_MAXB];
     double cx[FFL_MAXB], cy[FFL_MAXB];
 };
-void ffl_launch_radial(RadialTab rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st);
+void ffl_launch_radial(const RadialTab *rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st);
 
 // XCD-aware tile order (speed only, never correctness).  Workgroups are dealt round-robin over the 8
 // XCDs, so linear ids l and l+8 share an L2.  Each XCD gets one contiguous run of tiles, walked in

@@ -82,7 +82,7 @@ __device__ __forceinline__ void ffl_resize_coord(int d, int src, double scale, i
 constexpr int ffl_pyr_rows(int R) { return R == 1 ? 16 : (R == 4 ? 8 : 4); }
 constexpr int ffl_pyr_vrows(int R) { return R == 1 ? 4 : 1; }  // output rows per lane of k_pyr_v
 template <int R>
-__global__ __launch_bounds__(256) void k_pyr_h(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut, int w,
+__global__ __launch_bounds__(256) void k_pyr_h(const uint8_t *__restrict__ gray_base, size_t gray_stride, const UTab *__restrict__ ut, int w,
                                                int h, int lw, int nq, double sx, GaussKernel gk,
                                                float *__restrict__ tmp, size_t tmp_stride) {
     // each lane produces ROWS rows of its column (one workgroup per 256 outputs would be bound by the
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_pyr_h(const uint8_t *__restrict__ gray_
             xp[t - 1] = ffl_reflect101(cx + t, w);
         }
     }
-    const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
+    const uint8_t *img = gray_base + (size_t)ut->fslot[u] * gray_stride;
     float *out = tmp + (size_t)u * tmp_stride + i;
     const int ybase = blockIdx.y * ROWS;
     // word-wise tap fetch needs 4-byte aligned rows (w % 4 == 0; frame slots are w*h apart) and all
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_pyr_v(const float *__restrict__ tmp, si
 // load -- 10 / 20 loads per output pixel at R = 4 / 9 instead of 36 / 76.  Same operations in the same
 // order as k_pyr_h / k_pyr_v; lanes at the image border fall back to the per-sample form.
 template <int R>
-__device__ __forceinline__ void k_pyr_h2_body(const unsigned bx, const unsigned by, const unsigned bz, const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut, int w,
+__device__ __forceinline__ void k_pyr_h2_body(const unsigned bx, const unsigned by, const unsigned bz, const uint8_t *__restrict__ gray_base, size_t gray_stride, const UTab *__restrict__ ut, int w,
                                                 int h, int lw, double sx, GaussKernel gk, float *__restrict__ tmp,
                                                 size_t tmp_stride) {
     constexpr int ROWS = ffl_pyr_rows(R);
@@ -236,7 +236,7 @@ __device__ __forceinline__ void k_pyr_h2_body(const unsigned bx, const unsigned 
             xm[q][t - 1] = ffl_reflect101((q ? x1 : x0) - t, w);
             xp[q][t - 1] = ffl_reflect101((q ? x1 : x0) + t, w);
         }
-    const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
+    const uint8_t *img = gray_base + (size_t)ut->fslot[u] * gray_stride;
     float2 *out = reinterpret_cast<float2 *>(tmp + (size_t)u * tmp_stride) + d;
     const int ybase = by * ROWS;
 #pragma unroll
@@ -275,7 +275,7 @@ __device__ __forceinline__ void k_pyr_h2_body(const unsigned bx, const unsigned 
     }
 }
 template <int R>
-__global__ __launch_bounds__(256) void k_pyr_h2(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut, int w,
+__global__ __launch_bounds__(256) void k_pyr_h2(const uint8_t *__restrict__ gray_base, size_t gray_stride, const UTab *__restrict__ ut, int w,
                                                 int h, int lw, double sx, GaussKernel gk, float *__restrict__ tmp,
                                                 size_t tmp_stride) {
     k_pyr_h2_body<R>(blockIdx.x, blockIdx.y, blockIdx.z, gray_base, gray_stride, ut, w, h, lw, sx, gk, tmp, tmp_stride);
@@ -347,13 +347,13 @@ __global__ __launch_bounds__(256) void k_pyr_v2(const float *__restrict__ tmp, s
 // k_pyr_h + k_pyr_v (for S = 2 the lerp weights are exactly 0.5, for S = 1 the lerps are identities).
 #define FFL_PYR_FROWS 4
 template <int S>
-__global__ __launch_bounds__(256) void k_pyr_fused3(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
+__global__ __launch_bounds__(256) void k_pyr_fused3(const uint8_t *__restrict__ gray_base, size_t gray_stride, const UTab *__restrict__ ut,
                                                     int w, int h, int lw, int lh, GaussKernel gk,
                                                     float *__restrict__ I, size_t I_stride) {
     constexpr int NR = S * FFL_PYR_FROWS + 2;  // source rows per lane
     const int dx = blockIdx.x * 256 + threadIdx.x, u = blockIdx.z;
     if (dx >= lw) return;
-    const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
+    const uint8_t *img = gray_base + (size_t)ut->fslot[u] * gray_stride;
     const int cx = S * dx;                       // first sampled column; S == 2 also samples cx + 1
     const int first = cx - 1, woff = first & 3, wbase = first - woff;
     const bool wide = first >= 0 && cx + S < w && (w & 3) == 0;  // taps cx-1 .. cx+S inside the row
@@ -403,14 +403,14 @@ __global__ __launch_bounds__(256) void k_pyr_fused3(const uint8_t *__restrict__ 
 // row come with ONE 12- / 16-byte load and the four results leave with one 16-byte store -- a sixth of
 // the vector-memory instructions of the pixel-per-lane kernel above, which spent its time issuing them.
 template <int S, int FR>
-__device__ __forceinline__ void k_pyr_fused3x4_body(const unsigned bx, const unsigned by, const unsigned bz, const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
+__device__ __forceinline__ void k_pyr_fused3x4_body(const unsigned bx, const unsigned by, const unsigned bz, const uint8_t *__restrict__ gray_base, size_t gray_stride, const UTab *__restrict__ ut,
                                                       int w, int h, int lw, int lh, GaussKernel gk,
                                                       float *__restrict__ I, size_t I_stride) {
     constexpr int NR = S * FR + 2;   // source rows per lane
     constexpr int NBY = 4 * S + 2;   // source bytes per row: columns cx-1 .. cx+4S
     const int dx = 4 * (bx * 256 + threadIdx.x), u = bz;
     if (dx >= lw) return;
-    const uint8_t *img = gray_base + (size_t)ut.fslot[u] * gray_stride;
+    const uint8_t *img = gray_base + (size_t)ut->fslot[u] * gray_stride;
     const int cx = S * dx;  // first sampled column, a multiple of 4
     const bool wide = cx >= 4 && cx + 4 * S + 4 <= w;  // the aligned words cx-4 .. cx+4S+3 are inside the row
     const float k0 = gk.k[1], k1 = gk.k[2];
@@ -469,7 +469,7 @@ __device__ __forceinline__ void k_pyr_fused3x4_body(const unsigned bx, const uns
     }
 }
 template <int S, int FR>
-__global__ __launch_bounds__(256) void k_pyr_fused3x4(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
+__global__ __launch_bounds__(256) void k_pyr_fused3x4(const uint8_t *__restrict__ gray_base, size_t gray_stride, const UTab *__restrict__ ut,
                                                       int w, int h, int lw, int lh, GaussKernel gk,
                                                       float *__restrict__ I, size_t I_stride) {
     k_pyr_fused3x4_body<S, FR>(blockIdx.x, blockIdx.y, blockIdx.z, gray_base, gray_stride, ut, w, h, lw, lh, gk, I, I_stride);
@@ -480,7 +480,7 @@ size_t ffl_pyr_tmp_floats(int w, int h, int lw) { return (size_t)h * lw * (lw !=
 // All levels' pyramid work in TWO launches (1-D grids cut into per-job ranges): phase A = the fused fine
 // levels + the horizontal passes of the resampling levels, phase B = their vertical passes.  Six small,
 // latency-bound launches (117 us back to back at 1080p) overlap inside two.
-__global__ __launch_bounds__(256) void k_pyr_multi(const uint8_t *__restrict__ gray_base, size_t gray_stride, UTab ut,
+__global__ __launch_bounds__(256) void k_pyr_multi(const uint8_t *__restrict__ gray_base, size_t gray_stride, const UTab *__restrict__ ut,
                                                    PyrJobs jobs) {
     int i = 0;
 #pragma unroll
@@ -510,7 +510,7 @@ static int ffl_pyr_kind(int w, int h, int lw, int lh, int ksize) {
     return -1;
 }
 
-bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, const PyrJob *lv,
+bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, const UTab *__restrict__ ut, int nU, int w, int h, const PyrJob *lv,
                           int n, hipStream_t st) {
     if (n > FFL_MAX_JOBS) return false;
     PyrJobs A = {}, B = {};
@@ -549,7 +549,7 @@ bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, UTab ut,
     return true;
 }
 
-void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, UTab ut, int nU, int w, int h, int lw, int lh,
+void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, const UTab *__restrict__ ut, int nU, int w, int h, int lw, int lh,
                           GaussKernel gk, float *tmp, size_t tmp_stride, float *I, size_t I_stride, hipStream_t st) {
     const int r = gk.ksize / 2, nq = lw != w ? 2 : 1;
     const double sx = (double)w / lw, sy = (double)h / lh;
@@ -795,7 +795,8 @@ void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stri
 // zero (coarsest level) and neither read nor written -- k_blur_solve overwrites it without reading it
 template <int MODE>
 __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict__ R, size_t R_stride, size_t plane,
-                                                         PairTab pt, float *__restrict__ M, size_t M_stride, int w,
+                                                         const PairTab *__restrict__ pt, int level,
+                                                         float *__restrict__ M, size_t M_stride, int w,
                                                          int h, int pw, int ph, double usx, double usy, int store_flow,
                                                          int nB, int order) {
     int b, tile_x, tile_y;
@@ -805,9 +806,9 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
     const int x = tile_x * 64 + 2 * (threadIdx.x & 31);
     if (x >= w) return;
     const bool second = x + 1 < w;
-    const float *R0 = R + (size_t)pt.u0[b] * R_stride, *R1 = R + (size_t)pt.u1[b] * R_stride;
-    float2 *flow = reinterpret_cast<float2 *>(pt.flow[b]);
-    const float2 *prev = reinterpret_cast<const float2 *>(pt.prev[b]);
+    const float *R0 = R + (size_t)pt->u0[b] * R_stride, *R1 = R + (size_t)pt->u1[b] * R_stride;
+    float2 *flow = reinterpret_cast<float2 *>(pt->flow[level][b]);
+    const float2 *prev = reinterpret_cast<const float2 *>(pt->flow[min(level + 1, FFL_MAX_LEVELS - 1)][b]);
     int xa0 = 0, xa1 = 0, xb0 = 0, xb1 = 0;
     float aa1 = 0.f, ab1 = 0.f;
     constexpr bool UPSAMPLE = MODE == 1;
@@ -877,18 +878,19 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
 static int g_tile_order = 0;
 void ffl_set_tile_order(int order) { g_tile_order = order; }
 
-void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, PairTab pt, int nB, float *M,
+void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, const PairTab *pt, int level, int nB,
+                                float *M,
                                 size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, int store_flow,
                                 hipStream_t st) {
     dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + 15) / 16, nB));
     if (pw > 0)
-        hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh,
+        hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R, R_stride, plane, pt, level, M, M_stride, lw, lh,
                            pw, ph, (double)pw / lw, (double)ph / lh, store_flow, nB, g_tile_order);
     else if (zero_flow)
-        hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh, 0, 0,
+        hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R, R_stride, plane, pt, level, M, M_stride, lw, lh, 0, 0,
                            1.0, 1.0, 0, nB, g_tile_order);
     else
-        hipLaunchKernelGGL(k_update_matrices<0>, grid, dim3(256), 0, st, R, R_stride, plane, pt, M, M_stride, lw, lh, 0, 0,
+        hipLaunchKernelGGL(k_update_matrices<0>, grid, dim3(256), 0, st, R, R_stride, plane, pt, level, M, M_stride, lw, lh, 0, 0,
                            1.0, 1.0, 0, nB, g_tile_order);
 }
 
@@ -981,7 +983,8 @@ void ffl_set_blur_rows(int n) { g_blur_rows = n; }
 template <bool UPDATE, int FIRST>
 __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) void k_blur_solve(
     const float *__restrict__ Min, float *__restrict__ Mout, size_t M_stride, const float *__restrict__ R, size_t R_stride,
-    size_t plane, PairTab pt, int w, int h, int nrb, int pw, int ph, double usx, double usy, int store_flow, int nB,
+    size_t plane, const PairTab *__restrict__ pt, int level, int w, int h, int nrb, int pw, int ph, double usx, double usy,
+    int store_flow, int nB,
     int order) {
     constexpr int TW = 64, TH = 16, LW = TW + 2 * FFL_WIN_R, LH = TH + 2 * FFL_WIN_R;
     constexpr int PX = 4;  // consecutive pixels per lane in phase H
@@ -1015,8 +1018,8 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
     const unsigned pitch = (unsigned)w * 4u;
     float carry[NG][NCARRY];
     const double scale = 1.0 / (FFL_WIN * FFL_WIN);
-    float2 *flow = reinterpret_cast<float2 *>(pt.flow[b]);
-    const float *R0 = R + (size_t)pt.u0[b] * R_stride, *R1 = R + (size_t)pt.u1[b] * R_stride;
+    float2 *flow = reinterpret_cast<float2 *>(pt->flow[level][b]);
+    const float *R0 = R + (size_t)pt->u0[b] * R_stride, *R1 = R + (size_t)pt->u1[b] * R_stride;
     float *Mo = Mout + (size_t)b * M_stride;
     // float2 sF[TH][FP] viewed as float4 pairs; row pitch 66 (not 64) float2 so that the 64 32-byte writes
     // of a wave (16 rows x 4 blocks, all at the same offset inside their 128-byte block) spread over the banks
@@ -1028,7 +1031,7 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
     __shared__ float sM34[FIRST ? 5 - GC : 1][FIRST ? TH : 1][FIRST ? UP : 1];  // channels GC .. 4
     float *sM012 = reinterpret_cast<float *>(&sS2[0][0][0]);                     // channels 0 .. GC-1: [GC][TH][UP]
     static_assert(GC * TH * UP * 4 <= (int)sizeof(sS2), "the first group's staged rows must fit the column sums");
-    const float2 *prevf = reinterpret_cast<const float2 *>(pt.prev[b]);
+    const float2 *prevf = reinterpret_cast<const float2 *>(pt->flow[min(level + 1, FFL_MAX_LEVELS - 1)][b]);
     // M of the tile rows whose phase-V index is jbase .. jbase+nrows-1 (image rows y0-7+jbase ..), all 78 columns
     // one item = two adjacent tile columns (2p, 2p+1) of one row: 39 x nrows items, two pixels per lane like the
     // standalone kernel (8-byte R0 loads, shared 16-byte R1 loads); columns clamped into the image that fall on
@@ -1230,29 +1233,30 @@ static int ffl_blur_rows_per_wg(int tiles_x, int tiles_y, int nB) {
 }
 
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
-                           size_t plane, PairTab pt, int nB, int lw, int lh, int update, int store_flow, hipStream_t st) {
+                           size_t plane, const PairTab *pt, int level, int nB, int lw, int lh, int update, int store_flow,
+                           hipStream_t st) {
     const int tiles_x = (lw + 63) / 64, tiles_y = (lh + 15) / 16;
     const int nrb = g_blur_rows > 0 ? g_blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB);
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (update)
-        hipLaunchKernelGGL((k_blur_solve<true, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, lw,
+        hipLaunchKernelGGL((k_blur_solve<true, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, level, lw,
                            lh, nrb, 0, 0, 1.0, 1.0, store_flow, nB, g_tile_order);
     else
         hipLaunchKernelGGL((k_blur_solve<false, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt,
-                           lw, lh, nrb, 0, 0, 1.0, 1.0, 1, nB, g_tile_order);
+                           level, lw, lh, nrb, 0, 0, 1.0, 1.0, 1, nB, g_tile_order);
 }
 
 // first iteration of a level with the initial UpdateMatrices folded in (pw > 0: initial flow = x2 upsample of
 // pt.prev, pw x ph; pw == 0: zero flow); writes the solved flow to pt.flow and the next M to Mout
-void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane, PairTab pt,
-                                 int nB, int lw, int lh, int pw, int ph, hipStream_t st) {
+void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane,
+                                 const PairTab *pt, int level, int nB, int lw, int lh, int pw, int ph, hipStream_t st) {
     const int tiles_x = (lw + 63) / 64, tiles_y = (lh + 15) / 16;
     const int nrb = g_blur_rows > 0 ? g_blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB);
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (pw > 0)
         hipLaunchKernelGGL((k_blur_solve<true, 1>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
-                           R_stride, plane, pt, lw, lh, nrb, pw, ph, (double)pw / lw, (double)ph / lh, 0, nB, g_tile_order);
+                           R_stride, plane, pt, level, lw, lh, nrb, pw, ph, (double)pw / lw, (double)ph / lh, 0, nB, g_tile_order);
     else
         hipLaunchKernelGGL((k_blur_solve<true, 2>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
-                           R_stride, plane, pt, lw, lh, nrb, 0, 0, 1.0, 1.0, 0, nB, g_tile_order);
+                           R_stride, plane, pt, level, lw, lh, nrb, 0, 0, 1.0, 1.0, 0, nB, g_tile_order);
 }

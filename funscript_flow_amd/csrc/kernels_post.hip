@@ -63,13 +63,13 @@ __device__ __forceinline__ double ffl_wave_sum_f64(double v) {
 
 // key = (bits(|div|) << 32) | (0xFFFFFFFF - flat index): the maximum key is the largest |div| and,
 // among equals, the smallest row-major index -- np.argmax's first-occurrence rule, order independent.
-__global__ __launch_bounds__(P1_THREADS) void k_pass1(PairTab pt, int w, int h, int pov_mode,
+__global__ __launch_bounds__(P1_THREADS) void k_pass1(const PairTab *__restrict__ pt, int w, int h, int pov_mode,
                                                       unsigned long long *__restrict__ pkey,
                                                       double *__restrict__ psum) {
     __shared__ unsigned long long skey[P1_THREADS / 64];
     __shared__ double ssum[P1_THREADS / 64];
     const int b = blockIdx.y;
-    const float2 *flow = reinterpret_cast<const float2 *>(pt.flow[b]);
+    const float2 *flow = reinterpret_cast<const float2 *>(pt->flow[0][b]);
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nstrips = (w + P1_STRIP - 1) / P1_STRIP, ngroups = (h + P1_RG - 1) / P1_RG;
     const int wid = blockIdx.x * (P1_THREADS / 64) + wv;  // wave-uniform
@@ -123,10 +123,9 @@ __global__ __launch_bounds__(P1_THREADS) void k_pass1(PairTab pt, int w, int h, 
     }
 }
 
-__global__ __launch_bounds__(P1_THREADS) void k_pass1_final(PairTab pt, int w, int h, int pov_mode, int nblk,
-                                                            const unsigned long long *__restrict__ pkey,
-                                                            const double *__restrict__ psum,
-                                                            ResTab results) {
+__global__ __launch_bounds__(P1_THREADS) void k_pass1_final(const PairTab *__restrict__ pt, int w, int h, int pov_mode,
+                                                            int nblk, const unsigned long long *__restrict__ pkey,
+                                                            const double *__restrict__ psum) {
     __shared__ unsigned long long skey[P1_THREADS / 64];
     __shared__ double ssum[P1_THREADS / 64];
     const int b = blockIdx.x;
@@ -156,28 +155,28 @@ __global__ __launch_bounds__(P1_THREADS) void k_pass1_final(PairTab pt, int w, i
             unsigned idx = 0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull);
             r.y = idx / w;
             r.x = idx - r.y * w;
-            r.div_val = ffl_div_at(reinterpret_cast<const float2 *>(pt.flow[b]), w, h, r.x, r.y);
+            r.div_val = ffl_div_at(reinterpret_cast<const float2 *>(pt->flow[0][b]), w, h, r.x, r.y);
         }
         r.pad = 0.f;
         r.mag_sum = sum;
-        *results.r[b] = r;
+        *pt->res[b] = r;
     }
 }
 
-void ffl_launch_pass1(PairTab pt, int nB, int w, int h, int pov_mode, unsigned long long *pkey, double *psum,
-                      ResTab results, hipStream_t st) {
+void ffl_launch_pass1(const PairTab *pt, int nB, int w, int h, int pov_mode, unsigned long long *pkey, double *psum,
+                      hipStream_t st) {
     int nblk = (ffl_strip_waves(w, h, P1_STRIP) + 3) / 4;
     hipLaunchKernelGGL(k_pass1, dim3(nblk, nB), dim3(P1_THREADS), 0, st, pt, w, h, pov_mode, pkey, psum);
-    hipLaunchKernelGGL(k_pass1_final, dim3(nB), dim3(P1_THREADS), 0, st, pt, w, h, pov_mode, nblk, pkey, psum, results);
+    hipLaunchKernelGGL(k_pass1_final, dim3(nB), dim3(P1_THREADS), 0, st, pt, w, h, pov_mode, nblk, pkey, psum);
 }
 
 // ---- pass 2: radial_motion_weighted, float64 ------------------------------------------------------
-__global__ __launch_bounds__(P1_THREADS) void k_radial(RadialTab rt, int w, int h, int pov_mode,
+__global__ __launch_bounds__(P1_THREADS) void k_radial(const RadialTab *__restrict__ rt, int w, int h, int pov_mode,
                                                        double *__restrict__ psum) {
     __shared__ double ssum[P1_THREADS / 64];
     const int b = blockIdx.y;
-    const float2 *flow = reinterpret_cast<const float2 *>(rt.flow[b]);
-    const double cx = rt.cx[b], cy = rt.cy[b];
+    const float2 *flow = reinterpret_cast<const float2 *>(rt->flow[b]);
+    const double cx = rt->cx[b], cy = rt->cy[b];
     const double dw = (double)w, dh = (double)h;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nstrips = (w + P2_STRIP - 1) / P2_STRIP, ngroups = (h + P1_RG - 1) / P1_RG;
@@ -229,7 +228,7 @@ __global__ __launch_bounds__(P1_THREADS) void k_radial_final(int w, int h, int n
     }
 }
 
-void ffl_launch_radial(RadialTab rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st) {
+void ffl_launch_radial(const RadialTab *rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st) {
     int nblk = (ffl_strip_waves(w, h, P2_STRIP) + 3) / 4;
     hipLaunchKernelGGL(k_radial, dim3(nblk, nB), dim3(P1_THREADS), 0, st, rt, w, h, pov_mode, psum);
     hipLaunchKernelGGL(k_radial_final, dim3(nB), dim3(P1_THREADS), 0, st, w, h, nblk, psum, out);

@@ -48,7 +48,7 @@ extern "C" {
 #define FFL_ERR_NO_DEVICE 3 /* no usable gfx950 device */
 #define FFL_ERR_STATE 4     /* slot not ready (e.g. result requested before ffl_flow_pairs) */
 
-#define FFL_MAX_BATCH 64    /* pairs per ffl_flow_pairs / ffl_radial call */
+#define FFL_MAX_BATCH 256   /* pairs per ffl_flow_pairs / ffl_radial call */
 
 typedef struct ffl_ctx ffl_ctx;
 

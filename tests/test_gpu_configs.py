@@ -204,7 +204,8 @@ def test_two_ranks_on_one_device_under_gloo(tmp_path):
 def test_batches_above_eight_pairs_small_sizes():
     """Batches of 17 .. 64 pairs at sizes where the oracle covers every pair (no parity test used a batch
     above 8), with the library's default fold threshold and with thresholds that fold every / some levels."""
-    for (w, h, B, fuse) in [(640, 360, 32, 10000), (640, 360, 32, 1), (256, 256, 64, 10000), (200, 120, 17, 2000)]:
+    for (w, h, B, fuse) in [(640, 360, 32, 10000), (640, 360, 32, 1), (256, 256, 64, 10000), (200, 120, 17, 2000),
+                            (256, 256, 256, 10000), (96, 80, 200, 10000)]:
         frames = sine_translate_frames(B + 1, w, h, seed=1, zoom=0.01)
         try:
             _capi.set_option("fuse_first", fuse)
@@ -216,3 +217,54 @@ def test_batches_above_eight_pairs_small_sizes():
         for j in range(B):
             assert np.array_equal(flows[j], orc.farneback(frames[j], frames[j + 1])), (w, h, B, fuse, j)
             _check_reductions_on_own_flow(None, j, recs[j], flows[j])
+
+
+def test_reference_operating_point_256x256_b256_against_goldens():
+    """FF:1057: every frame is resized to 256x256 before pairing -- the reference's real operating point.  One batch
+    of 256 pairs (FFL_MAX_BATCH) per launch sequence, replayed from the captured hipGraph: all 256 records and
+    scalars against the oracle goldens; the first step is the capture, the later ones are replays."""
+    W = H = B = 256
+    frames = sine_translate_frames(B + 1, W, H, seed=1)
+    gold = golden_check.load_golden(W, H, B, 1)
+    assert gold is not None
+    with _capi.Context(W, H, frame_slots=B + 2, flow_slots=2 * B, max_batch=B) as ctx:
+        ctx.upload_frames(0, list(frames))
+        for step in range(3):
+            slots = [(step % 2) * B + i for i in range(B)]
+            ctx.flow_pairs(list(range(B)), list(range(1, B + 1)), slots)
+            recs = ctx.pass1_results(slots, 7.0)
+            centers = pipeline.smooth_centers([(r[0], r[1]) for r in recs])
+            dots = []
+            for s0 in range(0, B, 64):
+                dots += ctx.radial(slots[s0:s0 + 64], centers[s0:s0 + 64], [r[4] for r in recs[s0:s0 + 64]], False)
+            status, detail = golden_check.check_batch(gold, frames, recs, dots, lambda j: ctx.download_flow(slots[j]))
+            assert status is not False, (step, detail)
+        dots256 = ctx.radial(slots, centers, [r[4] for r in recs], False)     # pass 2 for 256 pairs in one call
+        assert dots256 == dots
+
+
+def test_graph_replay_equals_eager_launches():
+    """ffl_set_option("graph"): the captured-graph path and the eager path give identical bits, over batches of
+    different shapes on one context (full batches, a ragged last batch, independent pairs, POV), several replays
+    each with different frame / flow slot tables."""
+    w, h, B = 160, 120, 6
+    fr = sine_translate_frames(40, w, h, seed=14, amp=(2.5, 1.5), period=11, zoom=0.02)
+    out = {}
+    try:
+        for graph in (1, 0):
+            _capi.set_option("graph", graph)
+            with _capi.Context(w, h, max_batch=B, frame_slots=2 * B + 2, flow_slots=pipeline.min_flow_slots(B)) as ctx:
+                eng = pipeline.PairEngine(ctx)
+                a = eng.process_chunk(fr)                        # 39 pairs: 6 full batches + a ragged one of 3
+                b = eng.process_chunk(fr[:20], pov_mode=True)
+                ctx.upload_frames(0, list(fr[:8]))
+                ctx.flow_pairs([0, 2, 4, 6], [1, 3, 5, 7], [0, 1, 2, 3])   # independent pairs: 8 unique frames
+                c = [ctx.download_flow(j) for j in range(4)]
+            out[graph] = (a, b, c)
+    finally:
+        _capi.set_option("graph", 1)
+    for x, y in zip(out[1][:2], out[0][:2]):
+        assert np.array_equal(x[0], y[0]) and [tuple(r) for r in x[1]] == [tuple(r) for r in y[1]]
+    for j in range(4):
+        assert np.array_equal(out[1][2][j], out[0][2][j])
+        assert np.array_equal(out[1][2][j], orc.farneback(fr[2 * j], fr[2 * j + 1]))
