@@ -164,3 +164,76 @@ def test_blur_solve_against_exact_window_sums(w, h):
     want = np.stack([(g11 * h2 - g12 * h1) * idet, (g22 * h1 - g12 * h2) * idet], -1)
     got = orc.blur_solve(M)
     assert np.allclose(got, want, rtol=2e-6, atol=1e-7)
+
+
+def _quadratic(h, w, coef, shift=(0.0, 0.0)):
+    a, bx, by, cxx, cyy, cxy = coef
+    y, x = np.mgrid[0:h, 0:w].astype(np.float64)
+    x, y = x - shift[0], y - shift[1]
+    return (a + bx * x + by * y + cxx * x * x + cyy * y * y + cxy * x * y).astype(np.float32)
+
+
+@pytest.mark.parametrize("d", [(1.5, -0.75), (-2.25, 0.5), (0.0, 3.0), (0.4, 0.0)])
+def test_exact_quadratic_pair_gives_the_displacement_after_one_iteration(d):
+    """I1(x) = I0(x - d) for an exact quadratic I0: PolyExp recovers the coefficients exactly in the interior, the
+    first-order coefficients differ by 2 A d everywhere, so UpdateMatrices (zero initial flow) yields a CONSTANT
+    field M = (G, G d) with G = A^T A, the box blur leaves it unchanged and the regularised 2x2 solve returns
+        flow = d * det / (det + 1e-3),   det = (cxx cyy - (cxy/2)^2)^2
+    at every interior pixel -- one level, one iteration, no under-estimate.  This pins the signs, the channel
+    order ([dy, dx, yy, xx, xy] -> r2..r6), the 0.5 / 0.25 factors of UpdateMatrices, the (g11, g12, g22, h1, h2)
+    layout of M, the 1/225 scale and the solve's output order (x-flow first) far tighter than translation
+    recovery on a texture (~6 % under-estimate)."""
+    h, w = 72, 88
+    coef = (40.0, 0.7, -0.4, 0.11, 0.07, 0.05)          # a, bx, by, cxx, cyy, cxy
+    s = 6.0                                               # curvatures scaled so that det = 0.077 >> the 1e-3 regulariser
+    coef = coef[:3] + tuple(c * s for c in coef[3:])
+    I0, I1 = _quadratic(h, w, coef), _quadratic(h, w, coef, shift=d)
+    R0, R1 = orc.polyexp(I0), orc.polyexp(I1)
+    M = orc.update_matrices(R0, R1, np.zeros((h, w, 2), np.float32))
+    flow = orc.blur_solve(M)
+    cxx, cyy, r6 = coef[3], coef[4], coef[5] / 2
+    det = (cxx * cyy - r6 * r6) ** 2
+    want = np.array(d) * det / (det + 1e-3)
+    inner = flow[20:-20, 20:-20]                          # 5 (PolyExp) + 5 (border scaling) + 7 (box) pixels from every edge
+    assert np.allclose(inner[..., 0], want[0], rtol=2e-4, atol=2e-4), (inner[..., 0].mean(), want[0])
+    assert np.allclose(inner[..., 1], want[1], rtol=2e-4, atol=2e-4), (inner[..., 1].mean(), want[1])
+    # M itself: channels (g11, g12, g22, h1, h2) = (r4^2 + r6^2, (r4 + r5) r6, r5^2 + r6^2, r4 r2 + r6 r3, r6 r2 + r5 r3)
+    r2, r3 = cyy * d[1] + r6 * d[0], cxx * d[0] + r6 * d[1]
+    mid = M[:, 30, 40]
+    assert np.allclose(mid, [cyy * cyy + r6 * r6, (cyy + cxx) * r6, cxx * cxx + r6 * r6, cyy * r2 + r6 * r3, r6 * r2 + cxx * r3],
+                       rtol=3e-4)
+    # The exact displacement is a fixed point of the iteration: warping R1 by d cancels the first-order difference
+    # (r2 = r3 = 0 before the "+= r4 dy + r6 dx" terms put the whole displacement back), so UpdateMatrices at
+    # flow = d reproduces the same M -- h encodes the absolute displacement, not an increment.
+    M2 = orc.update_matrices(R0, R1, np.broadcast_to(np.float32(d), (h, w, 2)).copy())
+    assert np.allclose(M2[:, 24:-24, 24:-24], M[:, 24:-24, 24:-24], rtol=2e-3, atol=1e-5)
+
+
+def test_border_rules_reflect101_vs_replicate():
+    """Which border each stage uses decides the outermost pixels of every level: GaussianBlur REFLECT_101
+    (...cb|abc...), PolyExp and the 15x15 box REPLICATE (...aa|abc...).  Known answers on ramps."""
+    h, w = 64, 64
+    ramp = np.tile(np.arange(w, dtype=np.uint8)[None, :] * 2, (h, 1))      # I(x) = 2x
+    I = orc.pyr_level(ramp, 0)                                             # 3-tap [1/4, 1/2, 1/4], no resampling
+    assert np.all(I[:, 1:-1] == ramp[:, 1:-1])                             # a ramp is a fixed point inside
+    assert np.all(I[:, 0] == 1.0)        # REFLECT_101: (2 + 0 + 2) / 4 = 1   (REPLICATE would give 0.5)
+    assert np.all(I[:, -1] == ramp[0, -1] - 1.0)
+    rampy = np.ascontiguousarray(ramp.T)
+    Iy = orc.pyr_level(rampy, 0)
+    assert np.all(Iy[0, :] == 1.0) and np.all(Iy[1:-1] == rampy[1:-1])
+    # box filter: constant G = identity, h1 = ramp in x, h2 = 0  ->  flow_y = mean over the replicated window / (1 + 1e-3)
+    M = np.zeros((5, h, w), np.float32)
+    M[0] = M[2] = 1.0
+    M[3] = np.arange(w, dtype=np.float32)[None, :]
+    fy = orc.blur_solve(M)[..., 1]
+    x = np.arange(w)
+    win = np.clip(x[:, None] + np.arange(-7, 8)[None, :], 0, w - 1).mean(axis=1)    # REPLICATE
+    assert np.allclose(fy[10], win / (1.0 + 1e-3), rtol=1e-6)
+    assert abs(fy[10, 0] - (28 / 15) / 1.001) < 1e-6                       # 8 copies of 0, then 1..7
+    # PolyExp on a ramp: the x-derivative channel is exact inside; with REPLICATE columns it is under-estimated at
+    # the edge by a known amount: sum_k xg[k] * (min(k, .) - max(-k, .)) ...
+    R = orc.polyexp(np.tile(np.arange(w, dtype=np.float32)[None, :], (h, 1)))
+    g, xg, xxg, ig = orc.polyexp_constants()
+    assert np.allclose(R[1][20, 8:-8], 1.0, atol=1e-5)
+    b2_edge = sum(float(xg[k]) * (k - 0) for k in range(1, 6))            # row(p) - row(m) with m clamped to column 0
+    assert abs(R[1][20, 0] - b2_edge * ig[0]) < 1e-5
