@@ -134,9 +134,15 @@ class PairEngine:
             ctx.flow_pairs([resident[j] for j in js], [resident[j + 1] for j in js], [slot_of(l) for l in ls], pov_mode)
             return ls, js
 
+        release = getattr(frames, "release", None)  # prefetch.PrefetchRing views: frames may be recycled once consumed
+
         def collect(ls, js):
             got = ctx.pass1_results([slot_of(l) for l in ls], cut_threshold)  # one call per batch
             recs[ls[0]:ls[-1] + 1] = got
+            if release:
+                # this batch's kernels have run, so every transfer they waited for has left the host: frames up to
+                # the batch's last one will not be read from host memory again (ascending pair lists only)
+                release(js[-1] + 2)
             if on_batch:
                 on_batch(ls, js, got)
 

@@ -78,3 +78,46 @@ def test_frontend_errors_are_loud():
             ctx.upload_frames_raw(0, [f[:, :, 0]], (256, 256))        # not 3-channel
         with pytest.raises(_capi.FFLError):
             ctx.download_frame(1)                                      # never uploaded
+
+
+def test_video_to_actions_through_the_prefetch_ring():
+    """SURVEY 8(f) rank 4 end to end on the device: a (fake) capture is read sequentially into the context's
+    page-locked ring, frames go up in place (zero-copy path of ffl_upload_frames_raw), resize + gray on the device,
+    two-pass engine, post-chain -- and gives exactly the actions of the same engine fed a plain list of the decoded
+    frames.  60 fps source (every second frame is skipped with grab()), 3 chunks incl. a ragged one."""
+    from funscript_flow_amd import frontend, pipeline, prefetch
+    from funscript_flow_amd.synth import gray_to_bgr, sine_translate_frames
+    sw, sh, n, fps = 320, 240, 101, 60.0
+    src = gray_to_bgr(sine_translate_frames(n, sw, sh, seed=6, amp=(3.0, 2.0), period=24, zoom=0.03), gains=(0.9, 1.0, 0.8))
+
+    class Cap:
+        def __init__(self):
+            self.pos, self.seeks = 0, 0
+
+        def get(self, prop):
+            return {prefetch.CAP_PROP_FRAME_COUNT: n, prefetch.CAP_PROP_FPS: fps, prefetch.CAP_PROP_FRAME_WIDTH: sw,
+                    prefetch.CAP_PROP_FRAME_HEIGHT: sh}[prop]
+
+        def set(self, *a):
+            self.seeks += 1
+            return True
+
+        def grab(self):
+            self.pos += 1
+            return self.pos <= n
+
+        def read(self, image=None):
+            if self.pos >= n:
+                return False, None
+            np.copyto(image, src[self.pos])
+            self.pos += 1
+            return True, image
+
+    params = {"detrend_window": 1.0, "norm_window": 1.0, "batch_size": 20, "keyframe_reduction": False, "pov_mode": False}
+    cap = Cap()
+    with _capi.Context(128, 96, max_batch=4, frame_slots=10, flow_slots=pipeline.min_flow_slots(4)) as ctx:
+        got = prefetch.video_to_actions(ctx, cap, params)
+        eng = pipeline.PairEngine(ctx, frontend.DecodedUploader(ctx))
+        want = pipeline.frames_to_actions(eng, [src[i] for i in range(n)], fps, params)
+    assert cap.seeks == 0
+    assert got == want and len(got) == 48          # 51 sampled frames -> chunks of 20, 20, 11 -> 19 + 19 + 10 pairs
