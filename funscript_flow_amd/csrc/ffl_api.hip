@@ -39,7 +39,7 @@ static int g_merge_expand = 1;  // serial schedule: all levels' pyramid + PolyEx
 // graph changes from batch to batch.  Host time per batch drops from one launch call per kernel to one graph
 // launch -- what matters at the reference's 256x256 operating point, where a whole batch is a fraction of a ms.
 static int g_use_graph = 1;
-static int g_blur_rows_opt = 0, g_tile_order_opt = 0;  // mirrors of the kernel-side options (part of the graph key)
+static int g_opt_epoch = 0;  // bumped by every ffl_set_option: a captured graph is only replayed under the options it was captured with
 
 struct ProfRec {
     int cls;
@@ -84,7 +84,7 @@ struct ffl_ctx {
         BatchTab *d_tab = nullptr, *h_tab = nullptr;
         bool tab_used[FFL_EV_RING] = {false};
         struct GraphEntry {
-            int n, nU, pov, fuse_first, blur_rows, tile_order, merge_expand;
+            int n, nU, pov, epoch;
             hipGraph_t graph;
             hipGraphExec_t exec;
         };
@@ -895,11 +895,9 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     if (use_graph) {
         ffl_ctx::Lane::GraphEntry *ge = nullptr;
         for (auto &g : L.graphs)
-            if (g.n == n && g.nU == nU && g.pov == pov_mode && g.fuse_first == g_fuse_first && g.blur_rows == g_blur_rows_opt &&
-                g.tile_order == g_tile_order_opt && g.merge_expand == g_merge_expand)
-                ge = &g;
+            if (g.n == n && g.nU == nU && g.pov == pov_mode && g.epoch == g_opt_epoch) ge = &g;
         if (!ge) {
-            ffl_ctx::Lane::GraphEntry g = {n, nU, pov_mode, g_fuse_first, g_blur_rows_opt, g_tile_order_opt, g_merge_expand, nullptr, nullptr};
+            ffl_ctx::Lane::GraphEntry g = {n, nU, pov_mode, g_opt_epoch, nullptr, nullptr};
             HIPCHK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
             int rc = enqueue_batch(c, L, T, n, nU, pov_mode, nullptr);
             hipError_t ce = hipStreamEndCapture(st, &g.graph);
@@ -1114,6 +1112,7 @@ int ffl_sync(ffl_ctx *c) {
 
 int ffl_set_option(const char *name, int value) {
     if (!name) return FFL_ERR_INVALID;
+    g_opt_epoch++;
     if (!strcmp(name, "blur_tile_h")) {  // fixed: the box-sum order is anchored to blocks of 16 rows
         return value == 16 ? FFL_OK : FFL_ERR_INVALID;
     }
@@ -1129,13 +1128,15 @@ int ffl_set_option(const char *name, int value) {
     if (!strcmp(name, "blur_rows")) {  // tiles a k_blur_solve workgroup walks down: 0 automatic, 1..64
         if (value < 0 || value > 64) return FFL_ERR_INVALID;
         ffl_set_blur_rows(value);
-        g_blur_rows_opt = value;
         return FFL_OK;
     }
     if (!strcmp(name, "tile_order")) {  // 0 pair-major, 1 tile-major (ffl_tile_coord)
         if (value < 0 || value > 1) return FFL_ERR_INVALID;
         ffl_set_tile_order(value);
-        g_tile_order_opt = value;
+        return FFL_OK;
+    }
+    if (!strcmp(name, "pyr_coarse")) {  // 1 (default): one-pass kernel for the two coarse pyramid levels, 0: H + V kernel pairs
+        ffl_set_pyr_coarse(value != 0);
         return FFL_OK;
     }
     if (!strcmp(name, "graph")) {  // 1 (default): replay a batch's launches from a captured hipGraph, 0: launch eagerly

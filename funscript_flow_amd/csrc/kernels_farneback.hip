@@ -475,6 +475,180 @@ __global__ __launch_bounds__(256) void k_pyr_fused3x4(const uint8_t *__restrict_
     k_pyr_fused3x4_body<S, FR>(blockIdx.x, blockIdx.y, blockIdx.z, gray_base, gray_stride, ut, w, h, lw, lh, gk, I, I_stride);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The two coarse levels (x1/4 with a 9-tap blur, x1/8 with a 19-tap blur) from ONE pass over the gray frame:
+// a workgroup stages a 128 x 64 source tile (+ the 19-tap halo, REFLECT_101 applied while loading) in LDS with
+// coalesced dword loads, forms the horizontal blur at the sampled columns of BOTH levels into LDS, then the
+// vertical blur at the sampled rows and the two lerps.  No intermediate plane in memory (the H + V kernel pairs
+// above wrote and re-read 6 MB per 1080p frame) and one read of the frame instead of two strided ones.
+// Exact x4 / x8 decimation only (w, h multiples of 8): output d samples the source columns S*d + S/2 - 1 and
+// S*d + S/2 with weights 0.5 / 0.5 -- what ffl_resize_coord yields for these scales -- so the operations and
+// their order are those of k_pyr_h2 / k_pyr_v2.
+// ------------------------------------------------------------------------------------------------
+#define PC_TW 128
+#define PC_TH 64
+#define PC_PW 36   // staged tile: dwords per row (columns X0-8 .. X0+135)
+#define PC_PH 76   // rows Y0-6 .. Y0+69
+#define PC_H2R 70  // level-2 H rows: Y0-3 .. Y0+66
+#define PC_H2P 66  // pitch of sH2 (64 sampled columns + pad)
+#define PC_H3P 34  // pitch of sH3 (32 sampled columns + pad)
+__global__ __launch_bounds__(256) void k_pyr_coarse(const uint8_t *__restrict__ gray_base, size_t gray_stride,
+                                                    const UTab *__restrict__ ut, int w, int h, GaussKernel gk2,
+                                                    GaussKernel gk3, float *__restrict__ I2, size_t I2_stride,
+                                                    float *__restrict__ I3, size_t I3_stride, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(8))) uint32_t sP[PC_PH][PC_PW];
+    __shared__ __attribute__((aligned(8))) float sH2[PC_H2R][PC_H2P];
+    __shared__ __attribute__((aligned(8))) float sH3[PC_PH][PC_H3P];
+    const int tid = threadIdx.x;
+    const unsigned per = (unsigned)tiles_x * tiles_y;
+    const int u = blockIdx.x / per, t = blockIdx.x - u * per, ty = t / tiles_x, tx = t - ty * tiles_x;
+    const int X0 = tx * PC_TW, Y0 = ty * PC_TH;
+    const uint8_t *img = gray_base + (size_t)ut->fslot[u] * gray_stride;
+    // ---- stage the tile: 16 bytes per lane and load (the row segment X0-8 .. X0+135 is 9 such pieces), fixed trip
+    // count so that all loads of a lane are in flight together
+    constexpr int PCQ = PC_PW / 4, NLOAD = (PC_PH * PCQ + 255) / 256;
+    struct __attribute__((packed, aligned(4))) u4 { uint32_t a, b, c, d; };
+#pragma unroll
+    for (int k = 0; k < NLOAD; k++) {
+        const int i = tid + 256 * k;
+        if (i < PC_PH * PCQ) {
+            const int ry = i / PCQ, q = i - ry * PCQ;
+            const int gy = ffl_reflect101(Y0 - 6 + ry, h), X = X0 - 8 + 16 * q;
+            const uint8_t *row = img + (size_t)gy * w;
+            uint32_t v[4];
+            if (X >= 0 && X + 15 < w) {
+                const u4 t4 = *reinterpret_cast<const u4 *>(row + X);
+                v[0] = t4.a; v[1] = t4.b; v[2] = t4.c; v[3] = t4.d;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const int Xc = X + 4 * c;
+                    if (Xc >= 0 && Xc + 3 < w)  // w % 4 == 0: a dword is either inside the row or entirely outside
+                        v[c] = *reinterpret_cast<const uint32_t *>(row + Xc);
+                    else
+                        v[c] = (uint32_t)row[ffl_reflect101(Xc, w)] | ((uint32_t)row[ffl_reflect101(Xc + 1, w)] << 8) |
+                               ((uint32_t)row[ffl_reflect101(Xc + 2, w)] << 16) | ((uint32_t)row[ffl_reflect101(Xc + 3, w)] << 24);
+                }
+            }
+            *reinterpret_cast<uint2 *>(&sP[ry][4 * q]) = make_uint2(v[0], v[1]);
+            *reinterpret_cast<uint2 *>(&sP[ry][4 * q + 2]) = make_uint2(v[2], v[3]);
+        }
+    }
+    __syncthreads();
+    // ---- horizontal pass, level 2 (radius 4): output column dl samples tile bytes 4*dl+9, 4*dl+10 (image columns
+    // 4d+1, 4d+2); taps of both = bytes 4*dl+5 .. 4*dl+14 = dwords dl+1 .. dl+3
+    // (fixed trip counts + a row predicate: the loops unroll and a lane's LDS reads are in flight together)
+    {
+        const int dl = tid & 31, rr = tid >> 5;
+#pragma unroll 3
+        for (int k = 0; k < (PC_H2R + 7) / 8; k++) {
+            const int ry = rr + 8 * k;
+            if (ry < PC_H2R) {
+                const uint32_t *p = &sP[ry + 3][dl + 1];
+                const uint32_t d0 = p[0], d1 = p[1], d2 = p[2];
+                auto tap = [&](int j) {  // byte j of the 12 fetched ones; the first sample's centre is byte 5
+                    const uint32_t wd = j < 4 ? d0 : (j < 8 ? d1 : d2);
+                    return (float)((wd >> (8 * (j & 3))) & 255u);
+                };
+                float a0 = gk2.k[4] * tap(5), a1 = gk2.k[4] * tap(6);
+#pragma unroll
+                for (int j = 1; j <= 4; j++) {
+                    a0 = a0 + gk2.k[4 + j] * (tap(5 - j) + tap(5 + j));
+                    a1 = a1 + gk2.k[4 + j] * (tap(6 - j) + tap(6 + j));
+                }
+                *reinterpret_cast<float2 *>(&sH2[ry][2 * dl]) = make_float2(a0, a1);
+            }
+        }
+    }
+    // ---- horizontal pass, level 3 (radius 9): output column dl samples tile bytes 8*dl+11, 8*dl+12 (image columns
+    // 8d+3, 8d+4); taps of both = bytes 8*dl+2 .. 8*dl+21 = dwords 2*dl .. 2*dl+5
+    {
+        const int dl = tid & 15, rr = tid >> 4;
+#pragma unroll
+        for (int k = 0; k < (PC_PH + 15) / 16; k++) {
+            const int ry = rr + 16 * k;
+            if (ry < PC_PH) {
+                const uint32_t *p = &sP[ry][2 * dl];
+                uint32_t d[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) d[q] = p[q];
+                auto tap = [&](int j) { return (float)((d[j >> 2] >> (8 * (j & 3))) & 255u); };  // byte j of the 24
+                float a0 = gk3.k[9] * tap(11), a1 = gk3.k[9] * tap(12);
+#pragma unroll
+                for (int j = 1; j <= 9; j++) {
+                    a0 = a0 + gk3.k[9 + j] * (tap(11 - j) + tap(11 + j));
+                    a1 = a1 + gk3.k[9 + j] * (tap(12 - j) + tap(12 + j));
+                }
+                *reinterpret_cast<float2 *>(&sH3[ry][2 * dl]) = make_float2(a0, a1);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- vertical pass + lerps, level 2: 32 x 16 outputs, two per lane.  Output row el samples image rows
+    // 4e+1, 4e+2 = sH2 rows 4*el+4, 4*el+5; lerp weights are exactly 0.5 (a0 = 1 - a1 as in ffl_resize_coord's users)
+    {
+        const float a1 = 0.5f, a0 = 1.f - a1, b1 = 0.5f, b0 = 1.f - b1;
+        const int lw2 = w >> 2, lh2 = h >> 2;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int o = tid + 256 * k, el = o >> 5, dl = o & 31;
+            const int dx = (X0 >> 2) + dl, dy = (Y0 >> 2) + el;
+            float2 V[10];  // sH2 rows 4*el .. 4*el+9
+#pragma unroll
+            for (int j = 0; j < 10; j++) V[j] = *reinterpret_cast<const float2 *>(&sH2[4 * el + j][2 * dl]);
+            float tq[2];
+#pragma unroll
+            for (int qy = 0; qy < 2; qy++) {
+                const int c = 4 + qy;
+                float v0 = gk2.k[4] * V[c].x, v1 = gk2.k[4] * V[c].y;
+#pragma unroll
+                for (int j = 1; j <= 4; j++) {
+                    v0 = v0 + gk2.k[4 + j] * (V[c - j].x + V[c + j].x);
+                    v1 = v1 + gk2.k[4 + j] * (V[c - j].y + V[c + j].y);
+                }
+                tq[qy] = v0 * a0 + v1 * a1;
+            }
+            if (dx < lw2 && dy < lh2) I2[(size_t)u * I2_stride + (size_t)dy * lw2 + dx] = tq[0] * b0 + tq[1] * b1;
+        }
+    }
+    // ---- level 3: 16 x 8 outputs on the first 128 lanes.  Output row el samples image rows 8e+3, 8e+4 = sH3 rows
+    // 8*el+9, 8*el+10
+    if (tid < 128) {
+        const float a1 = 0.5f, a0 = 1.f - a1, b1 = 0.5f, b0 = 1.f - b1;
+        const int lw3 = w >> 3, lh3 = h >> 3;
+        const int el = tid >> 4, dl = tid & 15;
+        const int dx = (X0 >> 3) + dl, dy = (Y0 >> 3) + el;
+        float2 V[20];  // sH3 rows 8*el .. 8*el+19
+#pragma unroll
+        for (int j = 0; j < 20; j++) V[j] = *reinterpret_cast<const float2 *>(&sH3[8 * el + j][2 * dl]);
+        float tq[2];
+#pragma unroll
+        for (int qy = 0; qy < 2; qy++) {
+            const int c = 9 + qy;
+            float v0 = gk3.k[9] * V[c].x, v1 = gk3.k[9] * V[c].y;
+#pragma unroll
+            for (int j = 1; j <= 9; j++) {
+                v0 = v0 + gk3.k[9 + j] * (V[c - j].x + V[c + j].x);
+                v1 = v1 + gk3.k[9 + j] * (V[c - j].y + V[c + j].y);
+            }
+            tq[qy] = v0 * a0 + v1 * a1;
+        }
+        if (dx < lw3 && dy < lh3) I3[(size_t)u * I3_stride + (size_t)dy * lw3 + dx] = tq[0] * b0 + tq[1] * b1;
+    }
+}
+
+// true (and launched) when the x1/4 and x1/8 levels of a w x h frame can take the one-pass kernel
+bool ffl_launch_pyr_coarse(const uint8_t *gray_base, size_t gray_stride, const UTab *ut, int nU, int w, int h,
+                           const PyrJob &l2, const PyrJob &l3, hipStream_t st) {
+    if ((w & 7) || (h & 7) || l2.lw != w / 4 || l2.lh != h / 4 || l3.lw != w / 8 || l3.lh != h / 8 ||
+        l2.gk.ksize != 9 || l3.gk.ksize != 19)
+        return false;
+    const int tiles_x = (w + PC_TW - 1) / PC_TW, tiles_y = (h + PC_TH - 1) / PC_TH;
+    hipLaunchKernelGGL(k_pyr_coarse, dim3((unsigned)tiles_x * tiles_y * nU), dim3(256), 0, st, gray_base, gray_stride, ut, w,
+                       h, l2.gk, l3.gk, l2.I, l2.I_stride, l3.I, l3.I_stride, tiles_x, tiles_y);
+    return true;
+}
+
 size_t ffl_pyr_tmp_floats(int w, int h, int lw) { return (size_t)h * lw * (lw != w ? 2 : 1); }
 
 // All levels' pyramid work in TWO launches (1-D grids cut into per-job ranges): phase A = the fused fine
@@ -510,14 +684,29 @@ static int ffl_pyr_kind(int w, int h, int lw, int lh, int ksize) {
     return -1;
 }
 
+static int g_pyr_coarse = 1;
+void ffl_set_pyr_coarse(int on) { g_pyr_coarse = on; }
+
 bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, const UTab *__restrict__ ut, int nU, int w, int h, const PyrJob *lv,
                           int n, hipStream_t st) {
     if (n > FFL_MAX_JOBS) return false;
     PyrJobs A = {}, B = {};
     unsigned ta = 0, tb = 0;
+    for (int i = 0; i < n; i++)
+        if (ffl_pyr_kind(w, h, lv[i].lw, lv[i].lh, lv[i].gk.ksize) < 0) return false;
+    // the x1/8 and x1/4 levels (radius 9 and 4) in one pass over the frame where the sizes allow it
+    int skip0 = -1, skip1 = -1;
+    if (g_pyr_coarse)
+        for (int i = 0; i + 1 < n; i++)
+            if (lv[i].gk.ksize == 19 && lv[i + 1].gk.ksize == 9 &&
+                ffl_launch_pyr_coarse(gray_base, gray_stride, ut, nU, w, h, lv[i + 1], lv[i], st)) {
+                skip0 = i;
+                skip1 = i + 1;
+                break;
+            }
     for (int i = 0; i < n; i++) {
+        if (i == skip0 || i == skip1) continue;
         const int kind = ffl_pyr_kind(w, h, lv[i].lw, lv[i].lh, lv[i].gk.ksize);
-        if (kind < 0) return false;
         PyrJob J = lv[i];
         J.w = w;
         J.h = h;
@@ -613,18 +802,17 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, const UT
 #define PE_TH 16
 #define PE_N FFL_POLY_N
 #define PE_LW (PE_TW + 2 * PE_N)   // 74 tile columns incl. the halo
-#define PE_LP (PE_LW / 2)          // 37 column pairs
-#define PE_PITCH (PE_LW + 2)       // even row pitch: a pair never straddles an 8-byte boundary
+#define PE_LQ ((PE_LW + 3) / 4)    // 19 column quads
+#define PE_PITCH (4 * PE_LQ)       // 76: rows are whole quads, every quad 16-byte aligned
 
-// Two horizontally adjacent pixels per lane in every phase: the tile comes in with 8-byte loads, the
-// vertical pass reads / writes LDS 8 bytes at a time and its float arithmetic pairs up into packed
-// (v_pk_*) instructions, the horizontal pass fetches both pixels' taps with one LDS instruction and
-// stores 8 bytes per plane.  The kernel is VALU-bound (f32 taps + f64 accumulators), so instruction
-// count is what this buys.
+// Four horizontally adjacent pixels per lane in every phase.  The kernel is bound by instruction issue (f32 taps,
+// f64 accumulators, LDS reads), not by memory: with four pixels per lane the 14 taps a lane needs per plane come with
+// four LDS reads (3 x 16 B + 8 B) instead of the 22 dword reads two pixels needed, the tile comes in with 16-byte
+// global loads, and results leave with 16-byte stores.  Per pixel the operations and their order are unchanged.
 __device__ __forceinline__ void k_polyexp_body(const unsigned bx, const unsigned by, const unsigned bz, const float *__restrict__ I, size_t I_stride, float *__restrict__ R,
                                                  size_t R_stride, size_t plane, int w, int h, PolyConsts pc) {
-    __shared__ __attribute__((aligned(8))) float sI[PE_TH + 2 * PE_N][PE_PITCH];
-    __shared__ __attribute__((aligned(8))) float sV[3][PE_TH][PE_PITCH];
+    __shared__ __attribute__((aligned(16))) float sI[PE_TH + 2 * PE_N][PE_PITCH];
+    __shared__ __attribute__((aligned(16))) float sV[3][PE_TH][PE_PITCH];
     const int tid = threadIdx.x;
     const int u = bz;
     const int x0 = bx * PE_TW, y0 = by * PE_TH;
@@ -632,22 +820,23 @@ __device__ __forceinline__ void k_polyexp_body(const unsigned bx, const unsigned
 
     // fixed trip counts (+ a bounds predicate) so that the loops unroll: a rolled loop issues one
     // global load, waits for it, stores it to LDS, and only then issues the next
-    constexpr int N_IN = (PE_TH + 2 * PE_N) * PE_LP, N_V = PE_TH * PE_LP, N_OUT = PE_TH * (PE_TW / 2);
+    constexpr int N_IN = (PE_TH + 2 * PE_N) * PE_LQ, N_V = PE_TH * PE_LQ;
 #pragma unroll
     for (int it = 0; it < (N_IN + 255) / 256; it++) {
         const int i = tid + 256 * it;
         if (i < N_IN) {
-            const int ly = i / PE_LP, lx = 2 * (i - ly * PE_LP);
+            const int ly = i / PE_LQ, lx = 4 * (i - ly * PE_LQ);
             const int gy = min(max(y0 + ly - PE_N, 0), h - 1), gx = x0 + lx - PE_N;
             const float *row = img + (size_t)gy * w;
-            float2 t;
-            if (gx >= 0 && gx + 1 < w) {
-                const ffl_f2u q = *reinterpret_cast<const ffl_f2u *>(row + gx);
-                t = make_float2(q.x, q.y);
+            float4 t;
+            if (gx >= 0 && gx + 3 < w) {
+                const ffl_f4u q = *reinterpret_cast<const ffl_f4u *>(row + gx);
+                t = make_float4(q.x, q.y, q.z, q.w);
             } else {  // REPLICATE border
-                t = make_float2(row[min(max(gx, 0), w - 1)], row[min(max(gx + 1, 0), w - 1)]);
+                t = make_float4(row[min(max(gx, 0), w - 1)], row[min(max(gx + 1, 0), w - 1)],
+                                row[min(max(gx + 2, 0), w - 1)], row[min(max(gx + 3, 0), w - 1)]);
             }
-            *reinterpret_cast<float2 *>(&sI[ly][lx]) = t;
+            *reinterpret_cast<float4 *>(&sI[ly][lx]) = t;
         }
     }
     __syncthreads();
@@ -657,92 +846,96 @@ __device__ __forceinline__ void k_polyexp_body(const unsigned bx, const unsigned
     for (int it = 0; it < (N_V + 255) / 256; it++) {
         const int i = tid + 256 * it;
         if (i >= N_V) break;
-        const int ly = i / PE_LP, lx = 2 * (i - ly * PE_LP);
-        const float2 c = *reinterpret_cast<const float2 *>(&sI[ly + PE_N][lx]);
-        float2 r0 = make_float2(c.x * pc.g[0], c.y * pc.g[0]), r1 = make_float2(0.f, 0.f), r2 = make_float2(0.f, 0.f);
+        const int ly = i / PE_LQ, lx = 4 * (i - ly * PE_LQ);
+        const float4 c4 = *reinterpret_cast<const float4 *>(&sI[ly + PE_N][lx]);
+        const float c[4] = {c4.x, c4.y, c4.z, c4.w};
+        float r0[4], r1[4], r2[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            r0[e] = c[e] * pc.g[0];
+            r1[e] = 0.f;
+            r2[e] = 0.f;
+        }
 #pragma unroll
         for (int k = 1; k <= PE_N; k++) {
-            const float2 a = *reinterpret_cast<const float2 *>(&sI[ly + PE_N - k][lx]);
-            const float2 b = *reinterpret_cast<const float2 *>(&sI[ly + PE_N + k][lx]);
-            const float2 p = make_float2(a.x + b.x, a.y + b.y), d = make_float2(b.x - a.x, b.y - a.y);
-            r0 = make_float2(r0.x + pc.g[k] * p.x, r0.y + pc.g[k] * p.y);
-            r1 = make_float2(r1.x + pc.xg[k] * d.x, r1.y + pc.xg[k] * d.y);
-            r2 = make_float2(r2.x + pc.xxg[k] * p.x, r2.y + pc.xxg[k] * p.y);
+            const float4 a4 = *reinterpret_cast<const float4 *>(&sI[ly + PE_N - k][lx]);
+            const float4 b4 = *reinterpret_cast<const float4 *>(&sI[ly + PE_N + k][lx]);
+            const float a[4] = {a4.x, a4.y, a4.z, a4.w}, b[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const float p = a[e] + b[e], d = b[e] - a[e];
+                r0[e] = r0[e] + pc.g[k] * p;
+                r1[e] = r1[e] + pc.xg[k] * d;
+                r2[e] = r2[e] + pc.xxg[k] * p;
+            }
         }
-        *reinterpret_cast<float2 *>(&sV[0][ly][lx]) = r0;
-        *reinterpret_cast<float2 *>(&sV[1][ly][lx]) = r1;
-        *reinterpret_cast<float2 *>(&sV[2][ly][lx]) = r2;
+        *reinterpret_cast<float4 *>(&sV[0][ly][lx]) = make_float4(r0[0], r0[1], r0[2], r0[3]);
+        *reinterpret_cast<float4 *>(&sV[1][ly][lx]) = make_float4(r1[0], r1[1], r1[2], r1[3]);
+        *reinterpret_cast<float4 *>(&sV[2][ly][lx]) = make_float4(r2[0], r2[1], r2[2], r2[3]);
     }
     __syncthreads();
 
-    // horizontal part (double accumulators; the b2,b3,b5,b6 products are float products)
+    // horizontal part (double accumulators; the b2,b3,b5,b6 products are float products): one item = 4 pixels,
+    // 16 lanes per tile row, 256 items = one per lane
     float *out = R + (size_t)u * R_stride;
-#pragma unroll
-    for (int it = 0; it < N_OUT / 256; it++) {
-        const int i = tid + 256 * it;
-        const int ly = i / (PE_TW / 2), lx = 2 * (i - ly * (PE_TW / 2));
+    {
+        const int ly = tid >> 4, lx = 4 * (tid & 15);
         const int x = x0 + lx, y = y0 + ly;
-        if (x >= w || y >= h) continue;
-        const float *v0 = &sV[0][ly][lx + PE_N], *v1 = &sV[1][ly][lx + PE_N], *v2 = &sV[2][ly][lx + PE_N];
-        double b1[2], b2[2], b3[2], b4[2], b5[2], b6[2];
+        if (x >= w || y >= h) return;
+        float t[3][16];  // taps: tile columns lx .. lx+13 of the three planes (pixel e is centred at lx + 5 + e)
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+            const float *src = &sV[p][ly][lx];
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const float4 v = *reinterpret_cast<const float4 *>(src + 4 * q);
+                t[p][4 * q] = v.x; t[p][4 * q + 1] = v.y; t[p][4 * q + 2] = v.z; t[p][4 * q + 3] = v.w;
+            }
+            const float2 v2 = *reinterpret_cast<const float2 *>(src + 12);
+            t[p][12] = v2.x; t[p][13] = v2.y;
+        }
+        float o[5][4];
         const float g0c = pc.g[0];
 #pragma unroll
-        for (int e = 0; e < 2; e++) {
-            b1[e] = (double)(v0[e] * g0c);
-            b2[e] = 0;
-            b3[e] = (double)(v1[e] * g0c);
-            b4[e] = 0;
-            b5[e] = (double)(v2[e] * g0c);
-            b6[e] = 0;
-        }
+        for (int e = 0; e < 4; e++) {
+            const int c = PE_N + e;
+            double b1 = (double)(t[0][c] * g0c), b2 = 0, b3 = (double)(t[1][c] * g0c), b4 = 0, b5 = (double)(t[2][c] * g0c), b6 = 0;
 #pragma unroll
-        for (int k = 1; k <= PE_N; k++) {
-            const float gk = pc.g[k], xgk = pc.xg[k];
-            // both pixels' taps: v[k], v[k+1] and v[-k], v[-k+1]
-            const float p0[2] = {v0[k], v0[k + 1]}, m0[2] = {v0[-k], v0[-k + 1]};
-            const float p1[2] = {v1[k], v1[k + 1]}, m1[2] = {v1[-k], v1[-k + 1]};
-            const float p2[2] = {v2[k], v2[k + 1]}, m2[2] = {v2[-k], v2[-k + 1]};
-            float s0[2], d0[2], s1[2], d1[2], s2[2];
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                s0[e] = p0[e] + m0[e];
-                d0[e] = (p0[e] - m0[e]) * xgk;
-                s1[e] = (p1[e] + m1[e]) * gk;
-                d1[e] = (p1[e] - m1[e]) * xgk;
-                s2[e] = (p2[e] + m2[e]) * gk;
+            for (int k = 1; k <= PE_N; k++) {
+                const float gk = pc.g[k], xgk = pc.xg[k];
+                const float s0 = t[0][c + k] + t[0][c - k];
+                const float d0 = (t[0][c + k] - t[0][c - k]) * xgk;
+                const float s1 = (t[1][c + k] + t[1][c - k]) * gk;
+                const float d1 = (t[1][c + k] - t[1][c - k]) * xgk;
+                const float s2 = (t[2][c + k] + t[2][c - k]) * gk;
+                const double tg = (double)s0;
+                b1 += tg * pc.gd[k];
+                b4 += tg * pc.xxgd[k];
+                b2 += (double)d0;
+                b3 += (double)s1;
+                b6 += (double)d1;
+                b5 += (double)s2;
             }
-#pragma unroll
-            for (int e = 0; e < 2; e++) {
-                const double tg = (double)s0[e];
-                b1[e] += tg * pc.gd[k];
-                b4[e] += tg * pc.xxgd[k];
-                b2[e] += (double)d0[e];
-                b3[e] += (double)s1[e];
-                b6[e] += (double)d1[e];
-                b5[e] += (double)s2[e];
-            }
-        }
-        float o[5][2];
-#pragma unroll
-        for (int e = 0; e < 2; e++) {
-            o[0][e] = (float)(b3[e] * pc.ig11);
-            o[1][e] = (float)(b2[e] * pc.ig11);
-            o[2][e] = (float)(b1[e] * pc.ig03 + b5[e] * pc.ig33);
-            o[3][e] = (float)(b1[e] * pc.ig03 + b4[e] * pc.ig33);
-            o[4][e] = (float)(b6[e] * pc.ig55);
+            o[0][e] = (float)(b3 * pc.ig11);
+            o[1][e] = (float)(b2 * pc.ig11);
+            o[2][e] = (float)(b1 * pc.ig03 + b5 * pc.ig33);
+            o[3][e] = (float)(b1 * pc.ig03 + b4 * pc.ig33);
+            o[4][e] = (float)(b6 * pc.ig55);
         }
         const size_t off = (size_t)y * w + x;
-        if (x + 1 < w) {
+        if (x + 3 < w) {
 #pragma unroll
             for (int c = 0; c < 5; c++) {
-                ffl_f2u t;
-                t.x = o[c][0];
-                t.y = o[c][1];
-                *reinterpret_cast<ffl_f2u *>(out + c * plane + off) = t;
+                ffl_f4u q;
+                q.x = o[c][0]; q.y = o[c][1]; q.z = o[c][2]; q.w = o[c][3];
+                *reinterpret_cast<ffl_f4u *>(out + c * plane + off) = q;
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < 5; c++) out[c * plane + off] = o[c][0];
+            for (int c = 0; c < 5; c++)
+#pragma unroll
+                for (int e = 0; e < 4; e++)
+                    if (x + e < w) out[c * plane + off + e] = o[c][e];
         }
     }
 }

@@ -25,7 +25,7 @@ def post(golden_dir):
 
 
 # ------------------------------------------------------------------ per-kernel, per-level parity
-@pytest.mark.parametrize("w,h", [(96, 80), (320, 180), (250, 131)])
+@pytest.mark.parametrize("w,h", [(96, 80), (320, 180), (250, 131), (256, 256), (384, 264), (640, 360)])
 def test_farneback_stages_bit_exact(w, h):
     fr = frames(2, w, h, seed=21, amp=(3.0, 2.0), period=6)
     with _capi.Context(w, h, max_batch=1) as ctx:
@@ -215,3 +215,26 @@ def test_strip_walk_bit_exact(rows, fuse):
     finally:
         _capi.set_option("blur_rows", 0)
         _capi.set_option("fuse_first", 10000)
+
+
+@pytest.mark.parametrize("w,h", [(256, 256), (392, 264), (640, 360), (1920, 1080)])
+def test_one_pass_coarse_pyramid_levels_bit_exact(w, h):
+    """k_pyr_coarse (x1/4 and x1/8 levels from one LDS-staged pass over the frame; sizes with w, h multiples of 8):
+    level images of both frames against the oracle's pyr_level, incl. tiles cut by the right / bottom border and
+    the REFLECT_101 halo of every edge tile; the H + V kernel pairs (pyr_coarse = 0) give the same bits."""
+    fr = frames(2, w, h, seed=w + 3 * h, amp=(3.0, 2.0), period=6)
+    got = {}
+    try:
+        for on in (1, 0):
+            _capi.set_option("pyr_coarse", on)
+            with _capi.Context(w, h, max_batch=1) as ctx:
+                ctx.upload_frame(0, fr[0])
+                ctx.upload_frame(1, fr[1])
+                got[on] = {lvl: ctx.debug_pair(0, 1, lvl, 0) for lvl in (3, 2)}
+    finally:
+        _capi.set_option("pyr_coarse", 1)
+    for lvl in (3, 2):
+        for key, f in (("I0", fr[0]), ("I1", fr[1])):
+            want = orc.pyr_level(f, lvl)
+            assert np.array_equal(got[1][lvl][key], want), (lvl, key, np.abs(got[1][lvl][key] - want).max())
+            assert np.array_equal(got[0][lvl][key], want), (lvl, key)
