@@ -72,7 +72,7 @@ struct FrontParams {  // k_frontend: decoded 3-channel frame -> gray crop window
 enum { FFL_PYR_F1 = 0, FFL_PYR_F2, FFL_PYR_H4, FFL_PYR_H9, FFL_PYR_V4, FFL_PYR_V9 };
 struct PyrJob {  // one level of the pyramid (caller fills lw, lh, gk, tmp, tmp_stride, I, I_stride)
     int kind, w, h, lw, lh;
-    unsigned gx, gy, first;
+    unsigned gx, gy, first, count;  // grid of one frame, first block of the job, tiles of the job (all frames)
     double sx, sy;
     float *tmp, *I;
     size_t tmp_stride, I_stride;
@@ -87,7 +87,7 @@ struct PolyJob {  // one level of PolyExp (caller fills I, I_stride, R, R_stride
     float *R;
     size_t I_stride, R_stride, plane;
     int w, h;
-    unsigned gx, gy, first;
+    unsigned gx, gy, first, count;
 };
 struct PolyJobs {
     PolyJob j[FFL_MAX_JOBS];
@@ -134,6 +134,16 @@ struct RadialTab {  // device-resident like the batch tables
     double cx[FFL_MAXB], cy[FFL_MAXB];
 };
 void ffl_launch_radial(const RadialTab *rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st);
+
+// XCD-aware order of a 1-D run of `count` tiles: the l-th workgroup of the run (l and l+8 share an XCD under the
+// observed round-robin placement; the run must start at a multiple of 8) takes tile (l % 8) * chunk + l / 8, so every
+// XCD walks one contiguous piece of the run.  ffl_xcd_blocks(count) workgroups cover the run (up to 7 idle ones).
+static inline unsigned ffl_xcd_blocks(unsigned count) { return ((count + 7) / 8) * 8; }
+__device__ __forceinline__ bool ffl_xcd_tile(unsigned l, unsigned count, unsigned &t) {
+    const unsigned chunk = (count + 7) >> 3;
+    t = (l & 7u) * chunk + (l >> 3);
+    return (l >> 3) < chunk && t < count;
+}
 
 // XCD-aware tile order (speed only, never correctness).  Workgroups are dealt round-robin over the 8
 // XCDs, so linear ids l and l+8 share an L2.  Each XCD gets one contiguous run of tiles, walked in
