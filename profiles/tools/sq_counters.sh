@@ -8,7 +8,7 @@ P2="SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM_RD SQ_INST_CYCLES_VME
 P3="SQ_WAVE_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_IFETCH SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU"
 i=1
 for P in "$P1" "$P2" "$P3"; do
-  rocprofv3 --kernel-trace --pmc $P -d gpurun_out/pmc_sq$i -o sq --output-format csv -- python bench.py --no-cpu-baseline --no-events --steps 3 --warmup 1 > gpurun_out/pmc_sq$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $P -d gpurun_out/pmc_sq$i -o sq --output-format csv -- python3 bench.py --no-cpu-baseline --no-extras --no-events --steps 3 --warmup 1 > gpurun_out/pmc_sq$i.log 2>&1
   i=$((i+1))
 done
 python profiles/tools/sq_summary.py gpurun_out/pmc_sq1/sq_counter_collection.csv gpurun_out/pmc_sq2/sq_counter_collection.csv gpurun_out/pmc_sq3/sq_counter_collection.csv
