@@ -193,6 +193,18 @@ __device__ __forceinline__ bool ffl_tile_coord(int tiles_x, int tiles_y, int nB,
 struct __attribute__((packed, aligned(4))) ffl_f2u { float x, y; };
 struct __attribute__((packed, aligned(4))) ffl_f4u { float x, y, z, w; };
 
+// Element `idx` of a plane whose base is wave-uniform: base in scalar registers + a 32-bit per-lane byte offset -- the
+// global_load / global_store "saddr" form, no per-lane 64-bit address arithmetic (a tenth of UpdateMatrices' vector
+// instructions were 64-bit adds).  Offsets fit 32 bits: ffl_create rejects sizes with 20 * w * h >= 2^32.
+template <typename T>
+__device__ __forceinline__ const T *ffl_at(const float *base, unsigned idx) {
+    return reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + idx * 4u);
+}
+template <typename T>
+__device__ __forceinline__ T *ffl_at(float *base, unsigned idx) {
+    return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + idx * 4u);
+}
+
 // update-matrices body shared by the standalone kernel and the fused blur+solve+update kernel, in three
 // steps so that the R1 neighbourhood can be fetched in more than one way:
 //   ffl_um_locate   where pixel (x, y) displaced by (dx, dy) lands in R1 and its bilinear weights
@@ -221,11 +233,11 @@ __device__ __forceinline__ UmLoc ffl_um_locate(int w, int h, int x, int y, float
 // the two horizontally adjacent corners of a row with one 8-byte load each
 __device__ __forceinline__ void ffl_um_gather(const UmLoc &L, const float *__restrict__ R1, size_t plane, int w,
                                               float (&b)[5]) {
-    const float *p = R1 + (size_t)L.y1 * w + L.x1;
+    const unsigned o = (unsigned)L.y1 * (unsigned)w + (unsigned)L.x1;
 #pragma unroll
     for (int c = 0; c < 5; c++) {
-        const ffl_f2u t = *reinterpret_cast<const ffl_f2u *>(p + c * plane);      // (x1, y1), (x1+1, y1)
-        const ffl_f2u u = *reinterpret_cast<const ffl_f2u *>(p + c * plane + w);  // (x1, y1+1), (x1+1, y1+1)
+        const ffl_f2u t = *ffl_at<ffl_f2u>(R1 + c * plane, o);                 // (x1, y1), (x1+1, y1)
+        const ffl_f2u u = *ffl_at<ffl_f2u>(R1 + c * plane, o + (unsigned)w);   // (x1, y1+1), (x1+1, y1+1)
         b[c] = L.a00 * t.x + L.a01 * t.y + L.a10 * u.x + L.a11 * u.y;
     }
 }
@@ -274,18 +286,18 @@ __device__ __forceinline__ void ffl_um_finish(const float (&r0)[5], const float 
 __device__ __forceinline__ void ffl_um_pair_values(const float *__restrict__ R0, const float *__restrict__ R1,
                                                    size_t plane, int w, int h, int x, int y, float2 f0, float2 f1,
                                                    bool second, float (&ma)[5], float (&mb)[5]) {
-    const size_t o = (size_t)y * w + x;
+    const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
     float ra[5], rb[5];
     if (second) {
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            const ffl_f2u t = *reinterpret_cast<const ffl_f2u *>(R0 + c * plane + o);
+            const ffl_f2u t = *ffl_at<ffl_f2u>(R0 + c * plane, o);
             ra[c] = t.x;
             rb[c] = t.y;
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < 5; c++) ra[c] = rb[c] = R0[c * plane + o];
+        for (int c = 0; c < 5; c++) ra[c] = rb[c] = *ffl_at<float>(R0 + c * plane, o);
     }
     const int xb = second ? x + 1 : x;
     const UmLoc La = ffl_um_locate(w, h, x, y, f0.x, f0.y), Lb = ffl_um_locate(w, h, xb, y, f1.x, f1.y);
@@ -293,11 +305,11 @@ __device__ __forceinline__ void ffl_um_pair_values(const float *__restrict__ R0,
     const int dxx = Lb.x1 - La.x1;
     const bool span = La.inside && Lb.inside && La.y1 == Lb.y1 && (unsigned)dxx <= 2u && La.x1 + 3 < w;
     if (__all(span)) {
-        const float *p = R1 + (size_t)La.y1 * w + La.x1;
+        const unsigned o1 = (unsigned)La.y1 * (unsigned)w + (unsigned)La.x1;
 #pragma unroll
         for (int c = 0; c < 5; c++) {
-            const ffl_f4u t = *reinterpret_cast<const ffl_f4u *>(p + c * plane);      // row y1,   columns x1 .. x1+3
-            const ffl_f4u u = *reinterpret_cast<const ffl_f4u *>(p + c * plane + w);  // row y1+1
+            const ffl_f4u t = *ffl_at<ffl_f4u>(R1 + c * plane, o1);                // row y1,   columns x1 .. x1+3
+            const ffl_f4u u = *ffl_at<ffl_f4u>(R1 + c * plane, o1 + (unsigned)w);  // row y1+1
             ba[c] = La.a00 * t.x + La.a01 * t.y + La.a10 * u.x + La.a11 * u.y;
             const float t0 = dxx == 0 ? t.x : (dxx == 1 ? t.y : t.z), t1 = dxx == 0 ? t.y : (dxx == 1 ? t.z : t.w);
             const float u0 = dxx == 0 ? u.x : (dxx == 1 ? u.y : u.z), u1 = dxx == 0 ? u.y : (dxx == 1 ? u.z : u.w);
@@ -317,17 +329,17 @@ __device__ __forceinline__ void ffl_um_pair(const float *__restrict__ R0, const 
     float ma[5], mb[5];
     ffl_um_pair_values(R0, R1, plane, w, h, x, y, f0, f1, second, ma, mb);
     if (!store) return;
-    const size_t o = (size_t)y * w + x;
+    const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
     if (second) {
 #pragma unroll
         for (int c = 0; c < 5; c++) {
             ffl_f2u t;
             t.x = ma[c];
             t.y = mb[c];
-            *reinterpret_cast<ffl_f2u *>(Mo + c * plane + o) = t;
+            *ffl_at<ffl_f2u>(Mo + c * plane, o) = t;
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < 5; c++) Mo[c * plane + o] = ma[c];
+        for (int c = 0; c < 5; c++) *ffl_at<float>(Mo + c * plane, o) = ma[c];
     }
 }

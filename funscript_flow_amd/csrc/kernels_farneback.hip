@@ -58,6 +58,8 @@ __device__ __forceinline__ int ffl_reflect101(int p, int n) {
 
 // `scale` = (double)src / dst, formed once on the host (IEEE division: the same double the oracle forms)
 __device__ __forceinline__ void ffl_resize_coord(int d, int src, double scale, int &i0, int &i1, float &f) {
+    // (an integer fast path for the x2 upsample -- floor = (d - 1) >> 1, fraction 0.75 / 0.25 -- removes five f64-rate
+    // instructions per coordinate and made the folded k_blur_solve launch 2.5 % SLOWER: not kept)
     float fx = (float)((d + 0.5) * scale - 0.5);
     int sx = (int)floorf(fx);
     fx -= sx;
@@ -1040,10 +1042,12 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
             float b1;
             ffl_resize_coord(y, ph, usy, y0, y1, b1);
             const float b0 = 1.f - b1;
-            const float2 *r0p = prev + (size_t)y0 * pw, *r1p = prev + (size_t)y1 * pw;
+            const float *pf = reinterpret_cast<const float *>(prev);  // wave-uniform base + 32-bit offsets (ffl_at)
+            const unsigned r0o = (unsigned)y0 * (unsigned)pw, r1o = (unsigned)y1 * (unsigned)pw;
             {
                 const float a1 = aa1, a0 = 1.f - a1;
-                const float2 p00 = r0p[xa0], p01 = r0p[xa1], p10 = r1p[xa0], p11 = r1p[xa1];
+                const float2 p00 = *ffl_at<float2>(pf, 2u * (r0o + xa0)), p01 = *ffl_at<float2>(pf, 2u * (r0o + xa1)),
+                             p10 = *ffl_at<float2>(pf, 2u * (r1o + xa0)), p11 = *ffl_at<float2>(pf, 2u * (r1o + xa1));
                 float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
                 f0.x = (t0 * b0 + t1 * b1) * 2.0f;
                 t0 = p00.y * a0 + p01.y * a1;
@@ -1052,7 +1056,8 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
             }
             {
                 const float a1 = ab1, a0 = 1.f - a1;
-                const float2 p00 = r0p[xb0], p01 = r0p[xb1], p10 = r1p[xb0], p11 = r1p[xb1];
+                const float2 p00 = *ffl_at<float2>(pf, 2u * (r0o + xb0)), p01 = *ffl_at<float2>(pf, 2u * (r0o + xb1)),
+                             p10 = *ffl_at<float2>(pf, 2u * (r1o + xb0)), p11 = *ffl_at<float2>(pf, 2u * (r1o + xb1));
                 float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
                 f1.x = (t0 * b0 + t1 * b1) * 2.0f;
                 t0 = p00.y * a0 + p01.y * a1;
@@ -1252,8 +1257,10 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
         ffl_resize_coord(gx, pw, usx, xa0, xa1, a1);
         ffl_resize_coord(gy, ph, usy, ya0, ya1, b1);
         const float a0 = 1.f - a1, b0 = 1.f - b1;
-        const float2 *r0p = prevf + (size_t)ya0 * pw, *r1p = prevf + (size_t)ya1 * pw;
-        const float2 p00 = r0p[xa0], p01 = r0p[xa1], p10 = r1p[xa0], p11 = r1p[xa1];
+        const float *pf = reinterpret_cast<const float *>(prevf);  // wave-uniform base + 32-bit offsets (ffl_at)
+        const unsigned r0o = (unsigned)ya0 * (unsigned)pw, r1o = (unsigned)ya1 * (unsigned)pw;
+        const float2 p00 = *ffl_at<float2>(pf, 2u * (r0o + xa0)), p01 = *ffl_at<float2>(pf, 2u * (r0o + xa1)),
+                     p10 = *ffl_at<float2>(pf, 2u * (r1o + xa0)), p11 = *ffl_at<float2>(pf, 2u * (r1o + xa1));
         float2 f;
         float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
         f.x = (t0 * b0 + t1 * b1) * 2.0f;
