@@ -146,13 +146,15 @@ class StepRunner:
         self.ctx.sync()
 
 
-def resident_pass(W, H, B, steps, warmup, device, seed, events, independent=False, zoom=0.0, barrier=None, trace=False):
-    """The timed region of the contract on a fresh context: returns (dt, prof, runner, frames, level_sizes, U)."""
+def resident_pass(W, H, B, steps, warmup, device, seed, events, independent=False, zoom=0.0, barrier=None, trace=False,
+                  frames=None):
+    """The timed region of the contract on a fresh context: returns (dt, prof, runner, frames, level_sizes, U, ctx)."""
     from funscript_flow_amd import _capi
     from funscript_flow_amd.pipeline import SMOOTH_RADIUS
     from funscript_flow_amd.synth import sine_translate_frames
     U = 2 * B if independent else B + 1
-    frames = sine_translate_frames(U, W, H, seed=seed, zoom=zoom)
+    if frames is None:
+        frames = sine_translate_frames(U, W, H, seed=seed, zoom=zoom)
     ctx = _capi.Context(W, H, device=device, frame_slots=U + 1, flow_slots=3 * B, max_batch=B)
     level_sizes = [ctx.level_size(k) for k in range(ctx.num_levels() + 1)]
     ctx.upload_frames(0, list(frames))
@@ -192,15 +194,17 @@ def verify(runner, frames, W, H, B, seed, ctx):
     return golden_check.check_batch(gold, frames, recs, dots, lambda j: ctx.download_flow(slots[j]))
 
 
-def pcie_inclusive(W, H, B, device, seed, n_frames, bgr):
+def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None):
     """Host numpy frames -> per-pair scalars through pipeline.PairEngine: every frame crosses PCIe once (pinned
     staging copy + hipMemcpyAsync on the copy stream, overlapped with the previous batches' kernels)."""
     from funscript_flow_amd import _capi, pipeline
     from funscript_flow_amd.synth import gray_to_bgr, sine_translate_frames
-    base = sine_translate_frames(17, W, H, seed=seed)
+    if base is None:
+        base = sine_translate_frames(17, W, H, seed=seed)
+    base = base[:17]                                  # one period of the clip, cycled
     if bgr:
         base = gray_to_bgr(base)
-    frames = [base[i % 17] for i in range(n_frames)]
+    frames = [base[i % len(base)] for i in range(n_frames)]
     with _capi.Context(W, H, device=device, max_batch=B, frame_slots=2 * B + 2, flow_slots=pipeline.min_flow_slots(B)) as ctx:
         eng = pipeline.PairEngine(ctx)
         eng.process_chunk(frames[:2 * B + 1])  # warm-up
@@ -382,7 +386,8 @@ def main():
         if world == 1 and not args.no_extras:
             # (1) every kernel class under HIP events, in a pass of its own (the events cost ~0.2 ms per step)
             ksteps = max(3, min(args.steps, 6))
-            kdt, kprof, _, _, _, _, kctx = resident_pass(W, H, B, ksteps, 1, local_rank, seed, True, args.independent, args.zoom)
+            kdt, kprof, _, _, _, _, kctx = resident_pass(W, H, B, ksteps, 1, local_rank, seed, True, args.independent, args.zoom,
+                                                          frames=frames)
             kctx.close()
             out["kernel_classes"] = {
                 k: {"ms_per_step": v[1] / ksteps, "launches_per_step": v[0] / ksteps,
@@ -392,8 +397,9 @@ def main():
             # (2) PCIe-inclusive: host frames -> scalars (never `value`)
             _capi.set_option("lanes", 2)
             nfr = 8 * B + 1
-            out["pcie_inclusive"] = {"gray": pcie_inclusive(W, H, B, local_rank, seed, nfr, False),
-                                     "bgr": pcie_inclusive(W, H, B, local_rank, seed, nfr, True),
+            pbase = frames if (len(frames) >= 17 and not args.independent and args.zoom == 0.0) else None
+            out["pcie_inclusive"] = {"gray": pcie_inclusive(W, H, B, local_rank, seed, nfr, False, pbase),
+                                     "bgr": pcie_inclusive(W, H, B, local_rank, seed, nfr, True, pbase),
                                      "note": "pipeline.PairEngine, 2 compute lanes, pageable ndarrays copied into pinned staging"}
             _capi.set_option("lanes", args.lanes or 1)
             # (3) the reference's own operating point (FF:1057: every frame is resized to 256x256 first)
