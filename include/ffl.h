@@ -168,7 +168,14 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
  *   "lanes"       = 1..4     compute lanes (co-scheduled batches, each on its own stream and work
  *                            buffers) of contexts created afterwards; default 2
  *   "run_ahead"   = 0|1|2    schedule of the frame-only kernels: 0 serial (default), 1 run-ahead on a
- *                            side stream, 2 fork/join over per-level side streams */
+ *                            side stream, 2 fork/join over per-level side streams
+ *   "graph"       = 0|1      1 (default): a batch's launches are captured once per (lane, batch shape, option set)
+ *                            into a hipGraph and replayed; 0: launched one by one (timing events and the debug
+ *                            capture always launch one by one)
+ *   "pyr_coarse"  = 0|1      1 (default): the x1/4 and x1/8 pyramid levels of frames whose sides are multiples of 8
+ *                            come from one LDS-staged pass (k_pyr_coarse); 0: horizontal + vertical kernel pairs
+ *   "tile_order"  = 0|1      k_blur_solve / k_update_matrices workgroup order: 0 pair-major (default), 1 tile-major
+ *                            (every tile for all pairs of the batch back to back; less fabric traffic, not faster) */
 int ffl_set_option(const char *name, int value);
 
 /* HIP-event timing of kernel classes: every launch of a class whose bit (1u << FFL_K_*) is set in
