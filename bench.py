@@ -109,8 +109,10 @@ class StepRunner:
     """B-pair steps over U resident gray frames: enqueue / finalize with DEPTH batches queued ahead."""
     DEPTH = 2
 
-    def __init__(self, ctx, B, independent, smooth_radius):
+    def __init__(self, ctx, B, independent, smooth_radius, depth=None):
         self.ctx, self.B = ctx, B
+        if depth is not None:
+            self.DEPTH = depth
         if independent:
             self.f0, self.f1 = [2 * i for i in range(B)], [2 * i + 1 for i in range(B)]
         else:
@@ -147,7 +149,7 @@ class StepRunner:
 
 
 def resident_pass(W, H, B, steps, warmup, device, seed, events, independent=False, zoom=0.0, barrier=None, trace=False,
-                  frames=None):
+                  frames=None, depth=None):
     """The timed region of the contract on a fresh context: returns (dt, prof, runner, frames, level_sizes, U, ctx)."""
     from funscript_flow_amd import _capi
     from funscript_flow_amd.pipeline import SMOOTH_RADIUS
@@ -159,7 +161,7 @@ def resident_pass(W, H, B, steps, warmup, device, seed, events, independent=Fals
     level_sizes = [ctx.level_size(k) for k in range(ctx.num_levels() + 1)]
     ctx.upload_frames(0, list(frames))
     ctx.sync()
-    runner = StepRunner(ctx, B, independent, SMOOTH_RADIUS)
+    runner = StepRunner(ctx, B, independent, SMOOTH_RADIUS, depth)
     if warmup > 0:
         runner.run(warmup)
     runner.results.clear()
@@ -384,16 +386,18 @@ def main():
                            "achieved_GBps": sum(alg.values()) / B * (pairs / world) / dt / 1e9},
         }
         if world == 1 and not args.no_extras:
-            # (1) every kernel class under HIP events, in a pass of its own (the events cost ~0.2 ms per step)
+            # (1) every kernel class under HIP events, in a pass of its own (the events cost ~0.2 ms per step), one batch
+            # at a time (depth 0) so that pass 2 is not co-scheduled with the next batch's kernels: every class alone
             ksteps = max(3, min(args.steps, 6))
             kdt, kprof, _, _, _, _, kctx = resident_pass(W, H, B, ksteps, 1, local_rank, seed, True, args.independent, args.zoom,
-                                                          frames=frames)
+                                                          frames=frames, depth=0)
             kctx.close()
             out["kernel_classes"] = {
                 k: {"ms_per_step": v[1] / ksteps, "launches_per_step": v[0] / ksteps,
                     "alg_bytes_per_step": alg.get(k), "frac": (alg[k] / (v[1] / ksteps * 1e-3) / 1e9 / PEAK_GBPS) if k in alg and v[1] > 0 else None}
                 for k, v in kprof.items() if v[0]}
-            out["kernel_classes"]["_pass"] = {"steps": ksteps, "ms_per_step_with_events": kdt / ksteps * 1e3}
+            out["kernel_classes"]["_pass"] = {"steps": ksteps, "ms_per_step_unpipelined_with_events": kdt / ksteps * 1e3,
+                                              "note": "one batch at a time, host waits between batches: class times are those of each kernel running alone"}
             # (2) PCIe-inclusive: host frames -> scalars (never `value`)
             _capi.set_option("lanes", 2)
             nfr = 8 * B + 1

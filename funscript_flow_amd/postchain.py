@@ -104,6 +104,8 @@ def to_actions(values, frame_idx, fps, key_indices):
 def actions_from_scalars(dots, cuts, frame_idx, fps, params):
     """The whole chain for one video: params carries detrend_window / norm_window (seconds) and
     keyframe_reduction, exactly like the reference's settings dict (FF:2644-2662)."""
+    if len(dots) == 0:
+        return []  # no pair at all (a video of fewer than 2 sampled frames): the reference fails at FF:1268; nothing to write
     step = max(1, int(math.ceil(fps / 30.0)))
     effective_fps = fps / step
     cum = integrate(dots, cuts)

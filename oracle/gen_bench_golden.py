@@ -86,7 +86,9 @@ def generate(W, H, B, seed, threads=8):
         "made_by": "oracle/gen_bench_golden.py (C oracle farneback + numpy restatement of FF:748-785, FF:1203-1214)",
     }
     path = os.path.join(GOLD, golden_name(W, H, B, seed))
-    json.dump(out, open(path, "w"), indent=0)
+    with open(path, "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+        f.write("\n")
     print(path, "dots[0..2] =", dots[:3])
 
 

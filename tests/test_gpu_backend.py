@@ -363,3 +363,24 @@ class _SubCtx:
 
     def __getattr__(self, k):
         return getattr(self._c, k)
+
+
+def test_empty_and_minimal_chunks():
+    """Chunks of 0 / 1 / 2 frames (FF:1150: a chunk with fewer than 2 frames is skipped) and a chunk one pair longer
+    than a batch; the +-6 window is clipped to what exists."""
+    w, h = 96, 64
+    fr = sine_translate_frames(6, w, h, seed=2, amp=(2.0, 1.0), period=5)
+    with _capi.Context(w, h, max_batch=4, frame_slots=10, flow_slots=pipeline.min_flow_slots(4)) as ctx:
+        eng = pipeline.PairEngine(ctx)
+        for n_frames in (0, 1):
+            dots, recs = eng.process_chunk(fr[:n_frames])
+            assert len(dots) == 0 and recs == []
+        dots, recs = eng.process_chunk(fr[:2])
+        ref = orc.farneback(fr[0], fr[1])
+        ox, oy, _ = orc.max_divergence_np(ref)
+        assert (recs[0][0], recs[0][1]) == (ox, oy)
+        want = float(orc.radial_np(ref, (float(ox), float(oy)), recs[0][4]))       # a single pair is its own centre
+        assert abs(dots[0] - want) <= 1e-4 * max(abs(want), 1e-3)
+        dots6, recs6 = eng.process_chunk(fr)                                         # 5 pairs: one full batch + 1
+        assert len(dots6) == 5 and tuple(recs6[0]) == tuple(recs[0])
+        assert pipeline.frames_to_actions(eng, fr[:1], 30.0, {"batch_size": 10}) == []

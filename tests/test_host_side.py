@@ -226,3 +226,19 @@ def test_pair_engine_frame_ring_and_slot_bounds():
     import inspect
     src = inspect.getsource(_capi.Context.__init__)
     assert "2 * max_batch + 2" in src and "13 + 2 * max_batch" in src
+
+
+def test_create_rejects_bad_geometry_before_touching_a_device():
+    """Argument checks of ffl_create come before the device probe, so they are testable anywhere: sizes outside
+    16x16 .. 20*w*h < 2^32 (the kernels' 32-bit plane offsets), batch above FFL_MAX_BATCH, too few slots."""
+    for kw, frag in (({"width": 15, "height": 64}, "unsupported frame size"),
+                     ({"width": 16384, "height": 16384}, "unsupported frame size"),      # 20 * 2^28 >= 2^32
+                     ({"width": 64, "height": 64, "max_batch": _capi.FFL_MAX_BATCH + 1}, "bad slot/batch counts"),
+                     ({"width": 64, "height": 64, "frame_slots": 1}, "bad slot/batch counts"),
+                     ({"width": 64, "height": 64, "max_batch": 0}, "bad slot/batch counts")):
+        with pytest.raises(_capi.FFLError, match=frag):
+            _capi.Context(**kw)
+    assert _capi.FFL_MAX_BATCH == 256
+    hdr = open(os.path.join(ROOT, "include", "ffl.h")).read()
+    assert re.search(r"#define FFL_MAX_BATCH\s+256\b", hdr)
+    assert re.search(r"#define FFL_MAXB\s+256\b", open(os.path.join(ROOT, "funscript_flow_amd", "csrc", "ffl_kernels.h")).read())
