@@ -7,7 +7,7 @@ oracle (C restatement of cv2.calcOpticalFlowFarneback FF:878-879 + numpy restate
 FF:1203-1214).  bench.py compares its device results with this file after the timed region and reports
 `"checked": true`; the oracle itself never runs on the GPU box for that.
 
-    python oracle/gen_bench_golden.py [W H B [seed]]      default: the three bench workloads
+    python oracle/gen_bench_golden.py [W H B [seed]]      default: every golden the repo commits
 
 Writes tests/golden/bench_{W}x{H}_b{B}_s{seed}.json: crc32 of the input frames (the check is skipped, not
 failed, if numpy/libm on another machine rounds the synthetic texture differently), per pair (x, y, the f32
@@ -95,6 +95,9 @@ def generate(W, H, B, seed, threads=8):
 if __name__ == "__main__":
     if len(sys.argv) >= 4:
         generate(int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]) if len(sys.argv) > 4 else 1)
-    else:
-        generate(1920, 1080, 32, 1)
+    else:  # every golden the repo commits (about 8 minutes on 8 cores)
+        for seed in (1, 10, 11, 12, 13, 14, 15, 16, 17):     # N = 1 and the clips of ranks 0..7 of bench.py --gpus N
+            generate(1920, 1080, 32, seed)
+        generate(3840, 2160, 32, 1)
         generate(256, 256, 64, 1)
+        generate(256, 256, 256, 1)
