@@ -904,6 +904,13 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
             if (rc) return rc;
             HIPCHK(c, ce);
             HIPCHK(c, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+            if (L.graphs.size() >= 16) {  // bounded cache: callers that vary the batch shape a lot re-capture
+                // a replay may still be queued: graph resources are released once the lane's stream has drained
+                HIPCHK(c, hipStreamSynchronize(st));
+                hipGraphExecDestroy(L.graphs.front().exec);
+                hipGraphDestroy(L.graphs.front().graph);
+                L.graphs.erase(L.graphs.begin());
+            }
             L.graphs.push_back(g);
             ge = &L.graphs.back();
         }

@@ -268,3 +268,28 @@ def test_graph_replay_equals_eager_launches():
     for j in range(4):
         assert np.array_equal(out[1][2][j], out[0][2][j])
         assert np.array_equal(out[1][2][j], orc.farneback(fr[2 * j], fr[2 * j + 1]))
+
+
+def test_graph_cache_is_bounded_and_shapes_may_vary_freely():
+    """More batch shapes than the per-lane graph cache holds (16): every shape is captured, replayed, evicted and
+    re-captured without changing a bit (one lane so that all shapes land in the same cache)."""
+    w, h, nmax = 96, 64, 20
+    fr = sine_translate_frames(nmax + 1, w, h, seed=3, amp=(2.0, 1.0), period=7)
+    want = {}
+    try:
+        _capi.set_option("lanes", 1)
+        for graph in (0, 1):
+            _capi.set_option("graph", graph)
+            with _capi.Context(w, h, max_batch=nmax, frame_slots=nmax + 2, flow_slots=nmax) as ctx:
+                ctx.upload_frames(0, list(fr))
+                for rep in range(2):
+                    for n in list(range(1, nmax + 1)) + [3, 1, nmax]:
+                        ctx.flow_pairs(list(range(n)), list(range(1, n + 1)), list(range(n)))
+                        got = (ctx.download_flow(n - 1).tobytes(), tuple(ctx.pass1_result(n - 1)))
+                        if graph == 0 and rep == 0:
+                            want[n] = got
+                        assert got == want[n], (graph, rep, n)
+    finally:
+        _capi.set_option("graph", 1)
+        _capi.set_option("lanes", 2)
+    assert np.array_equal(np.frombuffer(want[nmax][0], np.float32).reshape(h, w, 2), orc.farneback(fr[nmax - 1], fr[nmax]))
