@@ -16,8 +16,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <condition_variable>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #define FFL_EV_RING 16
@@ -53,8 +55,93 @@ struct LevelGeom {
     GaussKernel gk;
 };
 
+// Staging copies (caller's pageable ndarray -> pinned memory) bound the PCIe-inclusive rate from 3-channel frames:
+// one host thread moves ~22 GB/s, a 1080p BGR stream at 5 k pairs/s needs 31.  A few persistent helper threads share
+// each large copy by rows (created on first use, joined in ffl_destroy).
+struct CopyPool {
+    struct Job {
+        uint8_t *dst;
+        const uint8_t *src;
+        size_t row_bytes;
+        ptrdiff_t dst_pitch, src_pitch;
+        int rows;
+    };
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<Job> jobs;   // one slot per worker
+    std::vector<char> busy;
+    bool stop = false;
+
+    static void run(const Job &j) {
+        if (j.dst_pitch == (ptrdiff_t)j.row_bytes && j.src_pitch == (ptrdiff_t)j.row_bytes)
+            memcpy(j.dst, j.src, j.row_bytes * (size_t)j.rows);
+        else
+            for (int y = 0; y < j.rows; y++) memcpy(j.dst + (ptrdiff_t)y * j.dst_pitch, j.src + (ptrdiff_t)y * j.src_pitch, j.row_bytes);
+    }
+    void start(int n) {
+        jobs.resize(n);
+        busy.assign(n, 0);
+        for (int i = 0; i < n; i++)
+            workers.emplace_back([this, i] {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    cv_work.wait(lk, [&] { return stop || busy[i]; });
+                    if (stop) return;
+                    Job j = jobs[i];
+                    lk.unlock();
+                    run(j);
+                    lk.lock();
+                    busy[i] = 0;
+                    cv_done.notify_all();
+                }
+            });
+    }
+    // rows x row_bytes from src (pitch src_pitch) to dst (pitch dst_pitch), split by rows over the helpers + the caller
+    void copy(uint8_t *dst, ptrdiff_t dst_pitch, const uint8_t *src, ptrdiff_t src_pitch, size_t row_bytes, int rows, int threads) {
+        const int parts = (row_bytes * (size_t)rows < (size_t)(1 << 20) || threads < 2) ? 1 : (threads < rows ? threads : rows);
+        if (parts > 1 && (int)workers.size() < parts - 1) {
+            // (re)size once; helpers are idle here because copy() is only called under the context lock
+            shutdown();
+            stop = false;
+            start(parts - 1);
+        }
+        const int per = (rows + parts - 1) / parts;
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            for (int p = 1; p < parts; p++) {
+                const int y0 = p * per, n = rows - y0 < per ? rows - y0 : per;
+                if (n <= 0) continue;
+                jobs[p - 1] = {dst + (ptrdiff_t)y0 * dst_pitch, src + (ptrdiff_t)y0 * src_pitch, row_bytes, dst_pitch, src_pitch, n};
+                busy[p - 1] = 1;
+            }
+            cv_work.notify_all();
+        }
+        run({dst, src, row_bytes, dst_pitch, src_pitch, per < rows ? per : rows});
+        if (parts > 1) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] {
+                for (char b : busy)
+                    if (b) return false;
+                return true;
+            });
+        }
+    }
+    void shutdown() {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            stop = true;
+            cv_work.notify_all();
+        }
+        for (auto &t : workers) t.join();
+        workers.clear();
+    }
+};
+static int g_copy_threads = 4;  // host threads sharing a staging copy (ffl_set_option "copy_threads", 1 = caller only)
+
 struct ffl_ctx {
     int device = 0, w = 0, h = 0, levels = 0;
+    CopyPool pool;
     int n_fslots = 0, n_slots = 0, max_batch = 0;
     size_t N = 0;
     LevelGeom geom[8];
@@ -359,6 +446,7 @@ void ffl_destroy(ffl_ctx *c) {
     if (c->s_post) hipStreamSynchronize(c->s_post);
     if (c->s_copy) hipStreamSynchronize(c->s_copy);
     prof_collect(c);
+    c->pool.shutdown();
     for (auto e : c->prof_pool) hipEventDestroy(e);
     for (auto &hb : c->host_bufs) hipHostFree(hb.first);
     for (auto e : c->up_ring)
@@ -564,35 +652,52 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
     // frames that sit back to back in one ffl_host_alloc buffer go to the device straight out of it
     bool direct = (size_t)stride_bytes == row && in_host_buf(c, frames[0], fbytes * n);
     for (int i = 1; direct && i < n; i++) direct = frames[i] == frames[0] + (size_t)i * fbytes;
-    for (int i = 0; i < n; i++) {
-        const int fs = first + i;
-        // the previous transfer out of this slot's staging areas must have left the host buffer
-        if (!direct && c->ev_uploaded[fs]) HIPCHK(c, hipEventSynchronize(c->ev_uploaded[fs]));
-        uint8_t *stage = stage0 + (size_t)i * fbytes;
-        const uint8_t *data = frames[i];
-        if (direct) {
-        } else if ((size_t)stride_bytes == row) memcpy(stage, data, row * height);
-        else
-            for (int y = 0; y < height; y++) memcpy(stage + (size_t)y * row, data + (ptrdiff_t)y * stride_bytes, row);
-        // the device copy of this slot may still be read by batches queued on any lane
+    // the device copies of these slots may still be read by batches queued on any lane
+    for (int i = 0; i < n; i++)
         for (size_t l = 0; l < c->lanes.size(); l++) {
-            hipEvent_t e = c->ev_last_use[(size_t)fs * c->lanes.size() + l];
+            hipEvent_t e = c->ev_last_use[(size_t)(first + i) * c->lanes.size() + l];
             if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
         }
-    }
-    uint8_t *gray = c->d_gray + (size_t)first * N;
-    const uint8_t *src0 = direct ? frames[0] : stage0;
-    if (channels == 1) {
-        HIPCHK(c, hipMemcpyAsync(gray, src0, N * n, hipMemcpyHostToDevice, c->s_copy));
+    // Staged frames go to the device in pieces of >= 8 MiB as soon as they are in pinned memory, so the transfer of
+    // the first frames runs while the host still copies the later ones (one 200 MB transfer issued after a 33-frame
+    // BGR run had been staged left the device waiting for it); small frames still travel as one run.
+    auto send = [&](int i0, int i1) -> int {  // frames i0 .. i1-1 of the run
+        uint8_t *gray = c->d_gray + (size_t)(first + i0) * N;
+        const uint8_t *src = (direct ? frames[0] : stage0) + (size_t)i0 * fbytes;
+        const int m = i1 - i0;
+        if (channels == 1) {
+            HIPCHK(c, hipMemcpyAsync(gray, src, N * m, hipMemcpyHostToDevice, c->s_copy));
+        } else {
+            uint8_t *bgr = c->d_bgr + (size_t)(first + i0) * N * 3;
+            HIPCHK(c, hipMemcpyAsync(bgr, src, N * 3 * m, hipMemcpyHostToDevice, c->s_copy));
+            ProfScope ps(c, FFL_K_GRAY, c->s_copy);
+            // k_gray counts pixels in 32 bits: runs of frames of at most 2^30 pixels per launch
+            const int per = (int)((size_t)(1u << 30) / N) > 0 ? (int)((size_t)(1u << 30) / N) : 1;
+            for (int i = 0; i < m; i += per) {
+                const int k = m - i < per ? m - i : per;
+                ffl_launch_gray(bgr + (size_t)i * N * 3, gray + (size_t)i * N, (int)(N * k), c->s_copy);
+            }
+        }
+        return FFL_OK;
+    };
+    if (direct) {
+        int rc = send(0, n);
+        if (rc) return rc;
     } else {
-        uint8_t *bgr = c->d_bgr + (size_t)first * N * 3;
-        HIPCHK(c, hipMemcpyAsync(bgr, src0, N * 3 * n, hipMemcpyHostToDevice, c->s_copy));
-        ProfScope ps(c, FFL_K_GRAY, c->s_copy);
-        // k_gray counts pixels in 32 bits: runs of frames of at most 2^30 pixels per launch
-        const int per = (int)((size_t)(1u << 30) / N) > 0 ? (int)((size_t)(1u << 30) / N) : 1;
-        for (int i = 0; i < n; i += per) {
-            const int m = n - i < per ? n - i : per;
-            ffl_launch_gray(bgr + (size_t)i * N * 3, gray + (size_t)i * N, (int)(N * m), c->s_copy);
+        int sent = 0;
+        size_t pending = 0;
+        for (int i = 0; i < n; i++) {
+            const int fs = first + i;
+            // the previous transfer out of this slot's staging area must have left the host buffer
+            if (c->ev_uploaded[fs]) HIPCHK(c, hipEventSynchronize(c->ev_uploaded[fs]));
+            c->pool.copy(stage0 + (size_t)i * fbytes, (ptrdiff_t)row, frames[i], stride_bytes, row, height, g_copy_threads);
+            pending += fbytes;
+            if (pending >= ((size_t)8 << 20) || i == n - 1) {
+                int rc = send(sent, i + 1);
+                if (rc) return rc;
+                sent = i + 1;
+                pending = 0;
+            }
         }
     }
     hipEvent_t ev = c->up_ring[c->up_next++ % (2 * FFL_EV_RING)];
@@ -652,9 +757,9 @@ int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *fr
         // a tightly packed frame in ffl_host_alloc memory goes to the device straight out of it
         const bool direct = (size_t)stride_bytes == fp.stride && in_host_buf(c, data, fbytes);
         if (direct) {
-        } else if ((size_t)stride_bytes == fp.stride) memcpy(rb.h, data, fbytes);
-        else
-            for (int y = 0; y < sh; y++) memcpy(rb.h + (size_t)y * fp.stride, data + (ptrdiff_t)y * stride_bytes, fp.stride);
+        } else {
+            c->pool.copy(rb.h, (ptrdiff_t)fp.stride, data, stride_bytes, fp.stride, sh, g_copy_threads);
+        }
         for (size_t l = 0; l < c->lanes.size(); l++) {  // batches still reading the slot's previous frame
             hipEvent_t e = c->ev_last_use[(size_t)fs * c->lanes.size() + l];
             if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
@@ -1144,6 +1249,11 @@ int ffl_set_option(const char *name, int value) {
     }
     if (!strcmp(name, "pyr_coarse")) {  // 1 (default): one-pass kernel for the two coarse pyramid levels, 0: H + V kernel pairs
         ffl_set_pyr_coarse(value != 0);
+        return FFL_OK;
+    }
+    if (!strcmp(name, "copy_threads")) {  // host threads sharing a staging copy of >= 1 MiB (1 = the caller alone)
+        if (value < 1 || value > 16) return FFL_ERR_INVALID;
+        g_copy_threads = value;
         return FFL_OK;
     }
     if (!strcmp(name, "graph")) {  // 1 (default): replay a batch's launches from a captured hipGraph, 0: launch eagerly

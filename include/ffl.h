@@ -169,6 +169,9 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
  *                            buffers) of contexts created afterwards; default 2
  *   "run_ahead"   = 0|1|2    schedule of the frame-only kernels: 0 serial (default), 1 run-ahead on a
  *                            side stream, 2 fork/join over per-level side streams
+ *   "copy_threads" = 1..16   host threads that share a staging copy of 1 MiB or more (the caller + helpers owned by
+ *                            the context); default 4.  One thread moves ~22 GB/s, a 1080p BGR stream at 5 k pairs/s
+ *                            needs 31
  *   "graph"       = 0|1      1 (default): a batch's launches are captured once per (lane, batch shape, option set)
  *                            into a hipGraph and replayed; 0: launched one by one (timing events and the debug
  *                            capture always launch one by one)

@@ -46,7 +46,7 @@ vals = {
     "L0C": f"{grid[('k_blur_solve<false, 0>', l0)]:.0f}",
     "KC_BS": f"{kc['k_blur_solve']['ms_per_step']:.2f}", "KC_PE": f"{kc['k_polyexp']['ms_per_step']:.2f}",
     "KC_PY": f"{kc['k_pyr_level']['ms_per_step']:.2f}", "KC_P1": f"{kc['k_pass1']['ms_per_step']:.2f}",
-    "KC_UM": f"{kc['k_update_matrices']['ms_per_step']:.2f}",
+    "KC_UM": f"{kc['k_update_matrices']['ms_per_step']:.2f}", "KC_RAD": f"{kc['k_radial']['ms_per_step']:.2f}",
     "WP": f"{b['whole_path']['achieved_GBps'] / 1e3:.2f}", "WPF": f"{b['whole_path']['achieved_GBps'] / 8000:.3f}",
     "LANES2": f"{J('bench_lanes2')['value']:.0f}", "B8": f"{J('bench_b8')['value']:.0f}",
     "ZOOM": f"{J('bench_zoom005')['value']:.0f}", "INDEP": f"{J('bench_independent')['value']:.0f}",
