@@ -419,6 +419,9 @@ def main():
                                       "whole_path_frac": sum(salg.values()) * 30 / sdt / 1e9 / PEAK_GBPS,
                                       "launch": "captured hipGraph replay per batch (no per-kernel events in this pass)",
                                       "checked": schk[0], "check_detail": schk[1]}
+                _capi.set_option("lanes", 2)
+                out["small_image"]["pcie_inclusive_gray"] = pcie_inclusive(256, 256, SB, local_rank, 1, 8 * SB + 1, False, sfr)
+                _capi.set_option("lanes", args.lanes or 1)
         if world == 1 and not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             threads = cores                              # the reference: Pool(os.cpu_count()) over pairs, FF:1190
