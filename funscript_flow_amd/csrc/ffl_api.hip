@@ -213,6 +213,7 @@ struct ffl_ctx {
     RadialTab *d_rtab = nullptr, *h_rtab = nullptr;    // pass-2 table (s_post; ffl_radial waits for the stream, so one copy)
     BatchTab *d_ptab = nullptr, *h_ptab = nullptr;     // ffl_upload_flow's one-pair table (s_post)
     double *d_rpsum = nullptr;                         // pass-2 partial sums (s_post)
+    double *d_wytab = nullptr;                         // pass-2 row weights (h - y) / h and y / h
     double *h_radial = nullptr, *d_radial = nullptr;   // pinned pass-2 results and their device alias
     unsigned long long *d_ppkey = nullptr;                                 // ffl_upload_flow scratch (s_post)
     int p1_blocks = 0;
@@ -479,7 +480,7 @@ void ffl_destroy(ffl_ctx *c) {
     hipFree(c->d_flow);
     hipHostFree(c->h_res);
     hipFree(c->d_rpsum); hipFree(c->d_ppkey); hipHostFree(c->h_radial);
-    hipFree(c->d_rtab); hipHostFree(c->h_rtab); hipFree(c->d_ptab); hipHostFree(c->h_ptab);
+    hipFree(c->d_rtab); hipHostFree(c->h_rtab); hipFree(c->d_ptab); hipHostFree(c->h_ptab); hipFree(c->d_wytab);
     if (c->s_copy) hipStreamDestroy(c->s_copy);
     if (c->s_post) hipStreamDestroy(c->s_post);
     delete c;
@@ -569,6 +570,15 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     CCHK(hipHostMalloc(&c->h_res, sizeof(Pass1Result) * n_flow_slots, hipHostMallocMapped));
     CCHK(hipHostGetDevicePointer((void **)&c->d_res, c->h_res, 0));
     CCHK(hipMalloc(&c->d_rpsum, sizeof(double) * c->p1_blocks * FFL_MAXB));
+    {
+        std::vector<double> wy(2 * (size_t)height);
+        for (int y = 0; y < height; y++) {
+            wy[y] = (double)(height - y) / (double)height;
+            wy[height + y] = (double)y / (double)height;
+        }
+        CCHK(hipMalloc(&c->d_wytab, sizeof(double) * wy.size()));
+        CCHK(hipMemcpy(c->d_wytab, wy.data(), sizeof(double) * wy.size(), hipMemcpyHostToDevice));
+    }
     CCHK(hipMalloc(&c->d_rtab, sizeof(RadialTab)));
     CCHK(hipHostMalloc(&c->h_rtab, sizeof(RadialTab), hipHostMallocDefault));
     CCHK(hipMalloc(&c->d_ptab, sizeof(BatchTab)));
@@ -1149,7 +1159,7 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
     {
         HIPCHK(c, hipMemcpyAsync(c->d_rtab, &rt, sizeof(RadialTab), hipMemcpyHostToDevice, st));
         ProfScope ps(c, FFL_K_RADIAL, st);
-        ffl_launch_radial(c->d_rtab, m, c->w, c->h, pov_mode, c->d_rpsum, c->d_radial, st);
+        ffl_launch_radial(c->d_rtab, m, c->w, c->h, pov_mode, c->d_wytab, c->d_rpsum, c->d_radial, st);
     }
     HIPCHK(c, hipStreamSynchronize(st));  // k_radial_final stored into the mapped pinned buffer
     HIPCHK(c, hipGetLastError());

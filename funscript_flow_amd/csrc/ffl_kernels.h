@@ -133,7 +133,9 @@ struct RadialTab {  // device-resident like the batch tables
     const float *flow[FFL_MAXB];
     double cx[FFL_MAXB], cy[FFL_MAXB];
 };
-void ffl_launch_radial(const RadialTab *rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st);
+// wytab: 2 * h doubles, [y] = (double)(h - y) / h, [h + y] = (double)y / h (the row weights of FF:780-783)
+void ffl_launch_radial(const RadialTab *rt, int nB, int w, int h, int pov_mode, const double *wytab, double *psum,
+                       double *out, hipStream_t st);
 
 // XCD-aware order of a 1-D run of `count` tiles: the l-th workgroup of the run (l and l+8 share an XCD under the
 // observed round-robin placement; the run must start at a multiple of 8) takes tile (l % 8) * chunk + l / 8, so every

@@ -2,17 +2,19 @@
 // FunscriptFlow.pyw:878-879).  Built with -ffp-contract=off: every float/double operation below is
 // meant literally, in the order written, so that results are bit-identical to the CPU oracle.
 //
-// Kernel            roofline   algorithmic bytes / level pixel
+// Kernel            bound      algorithmic bytes / level pixel
 //   k_gray          HBM        4 per full-res pixel (3 in, 1 out)
-//   k_pyr_*         HBM        1 per full-res pixel in + 4 per level pixel out ("k_pyr_level" class): fused 3-tap
-//                              kernels for the exact 1x / 2x levels (4 pixels per lane), H + V pair for the
-//                              resampling levels; all levels of a batch in two merged launches (k_pyr_multi)
-//   k_polyexp       VALU/HBM   24  (4 in, 20 out), 11x11 separable through LDS, f64 accumulators; all levels
-//                              in one merged launch (k_polyexp_multi)
+//   k_pyr_*         HBM / LDS  1 per full-res pixel in + 4 per level pixel out ("k_pyr_level" class): fused 3-tap
+//                              kernels for the exact 1x / 2x levels (4 pixels per lane, inside k_pyr_multi), one
+//                              LDS-staged pass for the x1/4 and x1/8 levels together (k_pyr_coarse), H + V kernel
+//                              pairs for geometries those do not cover
+//   k_polyexp       VALU(f64)  24  (4 in, 20 out), 11x11 separable through LDS, f64 accumulators, 4 pixels per
+//                              lane; all levels in one merged launch (k_polyexp_multi)
 //   k_update_mat    HBM        68  (R0 20 + R1 gather 20 + flow 8 -> M 20); also forms the level's
-//                              initial flow (x2 upsample: 2 in at quarter res + 8 out) in the same pass
+//                              initial flow (x2 upsample of the coarser level, used from registers)
 //   k_blur_solve    HBM        28  (M 20 -> flow 8) [+68 when the next UpdateMatrices is fused; on large
-//                              levels the first iteration also runs the level's flow init + UpdateMatrices_0]
+//                              levels the first iteration also runs the level's flow init + UpdateMatrices_0];
+//                              the flow is only stored by a level's last iteration (nothing reads it earlier)
 #include "ffl_kernels.h"
 
 // ------------------------------------------------------------------------------------------------

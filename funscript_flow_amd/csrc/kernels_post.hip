@@ -171,13 +171,17 @@ void ffl_launch_pass1(const PairTab *pt, int nB, int w, int h, int pov_mode, uns
 }
 
 // ---- pass 2: radial_motion_weighted, float64 ------------------------------------------------------
+// wytab[y] = (double)(h - y) / h, wytab[h + y] = (double)y / h: the two row weights of FF:780-783, formed once per
+// context on the host (IEEE division, the value the device's division yields).  The row index is wave-uniform, so the
+// weight comes with a scalar load instead of a 15-instruction f64 division per lane and row -- the kernel had
+// hoisted all 16 of them and needed 198 VGPRs (2 waves per SIMD).
 __global__ __launch_bounds__(P1_THREADS) void k_radial(const RadialTab *__restrict__ rt, int w, int h, int pov_mode,
-                                                       double *__restrict__ psum) {
+                                                       const double *__restrict__ wytab, double *__restrict__ psum) {
     __shared__ double ssum[P1_THREADS / 64];
     const int b = blockIdx.y;
     const float2 *flow = reinterpret_cast<const float2 *>(rt->flow[b]);
     const double cx = rt->cx[b], cy = rt->cy[b];
-    const double dw = (double)w, dh = (double)h;
+    const double dw = (double)w;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int nstrips = (w + P2_STRIP - 1) / P2_STRIP, ngroups = (h + P1_RG - 1) / P1_RG;
     const int wid = blockIdx.x * (P1_THREADS / 64) + wv;  // wave-uniform
@@ -190,17 +194,24 @@ __global__ __launch_bounds__(P1_THREADS) void k_radial(const RadialTab *__restri
         const double dx0 = (double)x - cx, dx1 = (double)(x + 1) - cx;
         const double wx0 = pov_mode ? 1.0 : (((double)x > cx) ? (double)(w - x) / dw : (double)x / dw);
         const double wx1 = pov_mode ? 1.0 : (((double)(x + 1) > cx) ? (double)(w - x - 1) / dw : (double)(x + 1) / dw);
+        // two groups of 8 rows: 8 row loads in flight per lane are enough to cover the latency, and the unrolled body
+        // stays within 4 waves per SIMD (all 16 rows hoisted needed 191 VGPRs)
+#pragma unroll 1
+        for (int g = 0; g < P1_RG; g += 8) {
+            float2 f0[8], f1[8];
 #pragma unroll
-        for (int r = 0; r < P1_RG; r++) {
-            const int y = y0 + r;
-            float2 f0, f1;
-            ffl_load_pair(flow, w, h, x, y, f0, f1);
-            const double dy = (double)y - cy;
-            const double wy = pov_mode ? 1.0 : (((double)y > cy) ? (double)(h - y) / dh : (double)y / dh);
-            const double t0 = ((double)f0.x * dx0 + (double)f0.y * dy) * wx0 * wy;
-            const double t1 = ((double)f1.x * dx1 + (double)f1.y * dy) * wx1 * wy;
-            sum += (ok0 && y < h) ? t0 : 0.0;
-            sum += (ok1 && y < h) ? t1 : 0.0;
+            for (int r = 0; r < 8; r++) ffl_load_pair(flow, w, h, x, y0 + g + r, f0[r], f1[r]);
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const int y = y0 + g + r;
+                const int yc = min(y, h - 1);  // rows past the image contribute nothing (predicated below)
+                const double dy = (double)y - cy;
+                const double wy = pov_mode ? 1.0 : (((double)y > cy) ? wytab[yc] : wytab[h + yc]);
+                const double t0 = ((double)f0[r].x * dx0 + (double)f0[r].y * dy) * wx0 * wy;
+                const double t1 = ((double)f1[r].x * dx1 + (double)f1[r].y * dy) * wx1 * wy;
+                sum += (ok0 && y < h) ? t0 : 0.0;
+                sum += (ok1 && y < h) ? t1 : 0.0;
+            }
         }
     }
     sum = ffl_wave_sum_f64(sum);
@@ -228,8 +239,9 @@ __global__ __launch_bounds__(P1_THREADS) void k_radial_final(int w, int h, int n
     }
 }
 
-void ffl_launch_radial(const RadialTab *rt, int nB, int w, int h, int pov_mode, double *psum, double *out, hipStream_t st) {
+void ffl_launch_radial(const RadialTab *rt, int nB, int w, int h, int pov_mode, const double *wytab, double *psum,
+                       double *out, hipStream_t st) {
     int nblk = (ffl_strip_waves(w, h, P2_STRIP) + 3) / 4;
-    hipLaunchKernelGGL(k_radial, dim3(nblk, nB), dim3(P1_THREADS), 0, st, rt, w, h, pov_mode, psum);
+    hipLaunchKernelGGL(k_radial, dim3(nblk, nB), dim3(P1_THREADS), 0, st, rt, w, h, pov_mode, wytab, psum);
     hipLaunchKernelGGL(k_radial_final, dim3(nB), dim3(P1_THREADS), 0, st, w, h, nblk, psum, out);
 }
