@@ -350,6 +350,10 @@ __global__ __launch_bounds__(256) void k_pyr_v2(const float *__restrict__ tmp, s
 // registers, then combined vertically -- no intermediate plane, same operations in the same order as
 // k_pyr_h + k_pyr_v (for S = 2 the lerp weights are exactly 0.5, for S = 1 the lerps are identities).
 #define FFL_PYR_FROWS 4
+#ifndef FFL_FR1
+#define FFL_FR1 8  // output rows per lane of the fused 3-tap kernels, level 0 / level 1 (33 x 1080p frames: 4/2 136 us,
+#define FFL_FR2 2  // 8/2 129, 12/2 136, 16/2 208, 8/4 256, 8/1 157, 2/2 175)
+#endif
 template <int S>
 __global__ __launch_bounds__(256) void k_pyr_fused3(const uint8_t *__restrict__ gray_base, size_t gray_stride, const UTab *__restrict__ ut,
                                                     int w, int h, int lw, int lh, GaussKernel gk,
@@ -644,12 +648,14 @@ __global__ __launch_bounds__(256) void k_pyr_coarse(const uint8_t *__restrict__ 
     }
 }
 
-// true (and launched) when the x1/4 and x1/8 levels of a w x h frame can take the one-pass kernel
+// true when the x1/4 and x1/8 levels of a w x h frame can take the one-pass kernel
+static bool ffl_pyr_coarse_ok(int w, int h, const PyrJob &l2, const PyrJob &l3) {
+    return !((w & 7) || (h & 7) || l2.lw != w / 4 || l2.lh != h / 4 || l3.lw != w / 8 || l3.lh != h / 8 ||
+             l2.gk.ksize != 9 || l3.gk.ksize != 19);
+}
 bool ffl_launch_pyr_coarse(const uint8_t *gray_base, size_t gray_stride, const UTab *ut, int nU, int w, int h,
                            const PyrJob &l2, const PyrJob &l3, hipStream_t st) {
-    if ((w & 7) || (h & 7) || l2.lw != w / 4 || l2.lh != h / 4 || l3.lw != w / 8 || l3.lh != h / 8 ||
-        l2.gk.ksize != 9 || l3.gk.ksize != 19)
-        return false;
+    if (!ffl_pyr_coarse_ok(w, h, l2, l3)) return false;
     const int tiles_x = (w + PC_TW - 1) / PC_TW, tiles_y = (h + PC_TH - 1) / PC_TH;
     hipLaunchKernelGGL(k_pyr_coarse, dim3(ffl_xcd_blocks((unsigned)tiles_x * tiles_y * nU)), dim3(256), 0, st, gray_base,
                        gray_stride, ut, w, h, l2.gk, l3.gk, l2.I, l2.I_stride, l3.I, l3.I_stride, tiles_x, tiles_y, nU);
@@ -673,8 +679,8 @@ __global__ __launch_bounds__(256) void k_pyr_multi(const uint8_t *__restrict__ g
     const unsigned per = J.gx * J.gy;
     const unsigned bz = t / per, r = t - bz * per, by = r / J.gx, bx = r - by * J.gx;
     switch (J.kind) {
-        case FFL_PYR_F1: k_pyr_fused3x4_body<1, 4>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.lh, J.gk, J.I, J.I_stride); break;
-        case FFL_PYR_F2: k_pyr_fused3x4_body<2, 2>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.lh, J.gk, J.I, J.I_stride); break;
+        case FFL_PYR_F1: k_pyr_fused3x4_body<1, FFL_FR1>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.lh, J.gk, J.I, J.I_stride); break;
+        case FFL_PYR_F2: k_pyr_fused3x4_body<2, FFL_FR2>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.lh, J.gk, J.I, J.I_stride); break;
         case FFL_PYR_H4: k_pyr_h2_body<4>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.sx, J.gk, J.tmp, J.tmp_stride); break;
         case FFL_PYR_H9: k_pyr_h2_body<9>(bx, by, bz, gray_base, gray_stride, ut, J.w, J.h, J.lw, J.sx, J.gk, J.tmp, J.tmp_stride); break;
         case FFL_PYR_V4: k_pyr_v2_body<4>(bx, by, bz, J.tmp, J.tmp_stride, J.w, J.h, J.lw, J.lh, J.sx, J.sy, J.gk, J.I, J.I_stride); break;
@@ -696,6 +702,7 @@ static int ffl_pyr_kind(int w, int h, int lw, int lh, int ksize) {
 static int g_pyr_coarse = 1;
 void ffl_set_pyr_coarse(int on) { g_pyr_coarse = on; }
 
+// (running the coarse kernel on a side stream beside the fine levels was tried: 5595 vs 5606 pairs/s, not kept)
 bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, const UTab *__restrict__ ut, int nU, int w, int h, const PyrJob *lv,
                           int n, hipStream_t st) {
     if (n > FFL_MAX_JOBS) return false;
@@ -723,7 +730,7 @@ bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, const UT
         J.sy = (double)h / J.lh;
         J.kind = kind;
         if (kind == FFL_PYR_F1 || kind == FFL_PYR_F2) {
-            const int fr = kind == FFL_PYR_F1 ? 4 : 2;
+            const int fr = kind == FFL_PYR_F1 ? FFL_FR1 : FFL_FR2;
             J.gx = (J.lw / 4 + 255) / 256;
             J.gy = (J.lh + fr - 1) / fr;
         } else {
@@ -754,7 +761,7 @@ void ffl_launch_pyr_level(const uint8_t *gray_base, size_t gray_stride, const UT
     const int r = gk.ksize / 2, nq = lw != w ? 2 : 1;
     const double sx = (double)w / lw, sy = (double)h / lh;
     if (r == 1 && ((lw == w && lh == h) || (w == 2 * lw && h == 2 * lh)) && (lw & 3) == 0 && (w & 3) == 0) {
-        constexpr int FR1 = 4, FR2 = 2;  // output rows per lane (H values held: 6 x 4 and 6 x 8 floats)
+        constexpr int FR1 = FFL_FR1, FR2 = FFL_FR2;  // output rows per lane
         if (lw == w) {
             dim3 grid((lw / 4 + 255) / 256, (lh + FR1 - 1) / FR1, nU);
             hipLaunchKernelGGL((k_pyr_fused3x4<1, FR1>), grid, dim3(256), 0, st, gray_base, gray_stride, ut, w, h, lw, lh,
