@@ -6,6 +6,8 @@ Same names, argument meaning and result shape as the reference's pair functions:
                                                            val_neg, cut, cut_center, mean_mag)
     precompute_wrapper(p, params)          FF:1019-1021
     radial_motion_weighted(flow, center, is_cut, pov_mode=False)   FF:761-785  -> float
+    precompute_all(pairs, params)          the whole `pool.starmap(precompute_wrapper, ...)` of FF:1190-1191
+    radial_all(precomputed, centers, pov_mode)   the whole ProcessPoolExecutor loop of FF:1232-1236
     get_available_backends()               FF:32-63  (reports "HIP" when a device is usable)
 
 Differences, all deliberate:
@@ -57,10 +59,11 @@ def _context(width, height, device=0):
 
 
 def release_contexts():
-    for c in _contexts.values():
+    for c in list(_contexts.values()) + list(_chunk_ctx.values()):
         c.close()
     _contexts.clear()
     _next_slot.clear()
+    _chunk_ctx.clear()
 
 
 def get_available_backends():
@@ -123,3 +126,97 @@ def radial_motion_weighted(flow, center, is_cut, pov_mode=False, device=0):
     ctx = _context(w, h, device)
     ctx.upload_flow(RING, flow, pov_mode)
     return np.float64(ctx.radial([RING], [center], [False], pov_mode)[0])
+
+
+# ---- the reference's two pool calls as two batched calls ------------------------------------------------
+_chunk_ctx = {}
+
+
+def _chunk_context(width, height, n_pairs, device, max_batch):
+    """A context whose flow slots hold a whole chunk (the reference keeps `precomputed`, flows included, for the
+    chunk: FF:1191-1236) -- grown on demand, reused across chunks."""
+    key = (width, height, device)
+    ctx = _chunk_ctx.get(key)
+    if ctx is None or ctx.flow_slots < n_pairs or ctx.max_batch != max_batch:
+        serial = getattr(ctx, "_chunk_serial", 0)
+        if ctx is not None:
+            ctx.close()
+            _chunk_ctx.pop(key, None)
+        need = 8.0 * width * height * n_pairs
+        if need > 200e9:
+            raise _capi.FFLError(f"a chunk of {n_pairs} pairs at {width}x{height} needs {need / 1e9:.0f} GB of resident flow: "
+                                 "lower batch_size (FF:2647) or use pipeline.PairEngine, which recycles flow slots")
+        ctx = _capi.Context(width, height, device=device, frame_slots=2 * max_batch + 2,
+                            flow_slots=max(n_pairs, 1), max_batch=max_batch)
+        ctx._chunk_serial = serial
+        _chunk_ctx[key] = ctx
+    ctx._chunk_serial += 1
+    return ctx
+
+
+class _ChunkFlow(DeviceFlow):
+    def _check(self):
+        if getattr(self.ctx, "_h", None) is None or self.ctx._chunk_serial != self.serial:
+            raise _capi.FFLError("DeviceFlow handle is stale: a later precompute_all() call reused the chunk's flow slots")
+
+
+def precompute_all(pairs, params):
+    """Drop-in for `pool.starmap(precompute_wrapper, [(p, params) for p in pairs])` (FF:1190-1191): the same list of
+    result dicts (FF:898-907), computed in batches of params.get("hip_batch", 32) pairs with consecutive pairs
+    sharing their frame (pairs = zip(frames[:-1], frames[1:]), FF:1188, is recognised by object identity); every
+    flow field stays resident until the next precompute_all() call, like the reference's `precomputed`."""
+    from . import pipeline
+    if params.get("backend", "HIP") != "HIP":
+        raise ValueError("funscript_flow_amd implements backend 'HIP' only")
+    pairs = list(pairs)
+    if not pairs:
+        return []
+    h, w = pairs[0][0].shape[:2]
+    B = max(1, min(int(params.get("hip_batch", 32)), _capi.FFL_MAX_BATCH))
+    ctx = _chunk_context(w, h, len(pairs), int(params.get("device", 0)), B)
+    # frames of the chunk in order of first use; a pair's two operands become frame indices
+    frames, index = [], {}
+    idx = []
+    for p0, p1 in pairs:
+        ij = []
+        for f in (p0, p1):
+            k = id(f)
+            if k not in index:
+                index[k] = len(frames)
+                frames.append(f)
+            ij.append(index[k])
+        idx.append(tuple(ij))
+    stream = all(b == a + 1 for a, b in idx) and all(idx[j + 1][0] == idx[j][1] for j in range(len(idx) - 1))
+    pov, thr = bool(params.get("pov_mode")), float(params.get("cut_threshold", 7))
+    eng = pipeline.PairEngine.__new__(pipeline.PairEngine)   # slots are sized for the chunk here, not for a stream
+    eng.ctx, eng.B, eng.upload = ctx, B, ctx.upload_frames
+    if stream:
+        recs = eng.pass1_pairs(frames, range(len(pairs)), lambda l: l, pov, thr)
+    else:  # arbitrary pairs: every pair brings its own two frames
+        flat = [f for p in pairs for f in p]
+        recs = eng.pass1_pairs(flat, range(0, 2 * len(pairs), 2), lambda l: l, pov, thr)
+    out = []
+    for l, (x, y, val, mean_mag, cut) in enumerate(recs):
+        pos_center = (np.int64(x), np.int64(y))
+        val_pos = 0 if pov else val                                   # FF:880-886
+        out.append({"flow": _ChunkFlow(ctx, l, ctx._chunk_serial), "pos_center": pos_center, "neg_center": pos_center,
+                    "val_pos": val_pos, "val_neg": val_pos, "cut": cut, "cut_center": pos_center[0], "mean_mag": mean_mag})
+    return out
+
+
+def radial_all(precomputed, centers, pov_mode=False):
+    """Drop-in for the ProcessPoolExecutor loop of FF:1232-1236: radial_motion_weighted(info["flow"], centers[j],
+    info["cut"], pov_mode) for every j, in batched device calls.  `precomputed` comes from precompute_all()."""
+    out = [0.0] * len(precomputed)
+    todo = [j for j, info in enumerate(precomputed) if not info["cut"]]
+    if not todo:
+        return out
+    ctx = precomputed[todo[0]]["flow"].ctx
+    for info in precomputed:
+        info["flow"]._check()
+    for s0 in range(0, len(todo), _capi.FFL_MAX_BATCH):
+        js = todo[s0:s0 + _capi.FFL_MAX_BATCH]
+        vals = ctx.radial([precomputed[j]["flow"].slot for j in js], [centers[j] for j in js], [False] * len(js), pov_mode)
+        for j, v in zip(js, vals):
+            out[j] = np.float64(v)
+    return out

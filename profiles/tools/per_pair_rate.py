@@ -32,5 +32,15 @@ for (w, h, n, B) in ((256, 256, 257, 256), (1920, 1080, 65, 32)):
         t0 = time.perf_counter()
         eng.process_chunk(frames)
         engine = (n - 1) / (time.perf_counter() - t0)
+    # the reference's two pool calls as two batched calls (backend.precompute_all / radial_all) with its own chunk code between
+    pairs = list(zip(frames[:-1], frames[1:]))
+    params = {"backend": "HIP", "hip_batch": B}
+    backend.precompute_all(pairs, params)  # warm-up: creates the chunk-sized context
+    t0 = time.perf_counter()
+    pre = backend.precompute_all(pairs, params)
+    centers = pipeline.smooth_centers([i["pos_center"] for i in pre])
+    backend.radial_all(pre, centers, False)
+    batched = (n - 1) / (time.perf_counter() - t0)
+    backend.release_contexts()
     print(json.dumps({"size": f"{w}x{h}", "per_pair_api_pairs_per_s": per_pair, "pair_engine_pairs_per_s": engine,
-                      "ratio": engine / per_pair, "engine_batch": B}))
+                      "precompute_all_radial_all_pairs_per_s": batched, "ratio": engine / per_pair, "engine_batch": B}))

@@ -384,3 +384,53 @@ def test_empty_and_minimal_chunks():
         dots6, recs6 = eng.process_chunk(fr)                                         # 5 pairs: one full batch + 1
         assert len(dots6) == 5 and tuple(recs6[0]) == tuple(recs[0])
         assert pipeline.frames_to_actions(eng, fr[:1], 30.0, {"batch_size": 10}) == []
+
+
+def test_precompute_all_and_radial_all_replace_the_two_pools(golden_dir):
+    """backend.precompute_all / radial_all = the reference's `pool.starmap(precompute_wrapper, ...)` (FF:1190-1191) and
+    its ProcessPoolExecutor loop (FF:1232-1236) as two batched calls, with the reference's own chunk code in between:
+    the per-pair dicts and scalars equal the chain captured from the real process_video."""
+    meta = json.load(open(os.path.join(golden_dir, "chain_golden.json")))
+    d = np.load(os.path.join(golden_dir, "chain_golden.npz"))
+    s = meta["synth"]
+    frames = sine_translate_frames(meta["n_frames"], meta["size"], meta["size"], seed=s["seed"], amp=tuple(s["amp"]),
+                                   period=s["period"], zoom=s["zoom"])
+    if zlib.crc32(frames.tobytes()) != meta["frames_crc32"]:
+        pytest.skip("synthetic frames differ from the ones the golden was captured on (libm/numpy difference)")
+    bs = meta["settings"]["batch_size"]
+    params = {"backend": "HIP", "hip_batch": 5}
+    pos, vals, cuts, mm, dots = [], [], [], [], []
+    for cs in range(0, meta["n_frames"], bs):
+        frames_gray = list(frames[cs:cs + bs])
+        if len(frames_gray) < 2:
+            continue
+        pairs = list(zip(frames_gray[:-1], frames_gray[1:]))                          # FF:1188
+        precomputed = backend.precompute_all(pairs, params)                           # FF:1190-1191
+        assert set(precomputed[0]) == {"flow", "pos_center", "neg_center", "val_pos", "val_neg", "cut", "cut_center", "mean_mag"}
+        centers = pipeline.smooth_centers([info["pos_center"] for info in precomputed])   # FF:1203-1214
+        dots += list(backend.radial_all(precomputed, centers, False))                 # FF:1232-1236
+        pos += [tuple(int(v) for v in info["pos_center"]) for info in precomputed]
+        vals += [np.float32(info["val_pos"]) for info in precomputed]
+        cuts += [info["cut"] for info in precomputed]
+        mm += [float(info["mean_mag"]) for info in precomputed]
+        j = len(pairs) // 2
+        assert np.array_equal(np.asarray(precomputed[j]["flow"]), orc.farneback(pairs[j][0], pairs[j][1]))
+    assert np.array_equal(np.array(pos), d["pos_center"]) and np.array_equal(np.array(vals), d["val_pos"])
+    assert np.array_equal(np.array(cuts), d["cut"]) and np.allclose(mm, d["mean_mag"], rtol=1e-4, atol=0)
+    scale = np.mean(np.abs(d["dots"]))
+    assert np.all(np.abs(np.array(dots) - d["dots"]) <= 1e-4 * np.maximum(np.abs(d["dots"]), scale))
+    # arbitrary (non-stream) pairs, BGR operands, POV, a cut, and a stale handle
+    w = h = meta["size"]
+    bgr = gray_to_bgr(frames[:6])
+    odd = [(bgr[4], bgr[1]), (bgr[0], bgr[5]), (bgr[2], bgr[2])]
+    pre = backend.precompute_all(odd, {"backend": "HIP", "pov_mode": True, "cut_threshold": 0.0})
+    for (a, b), info in zip(odd, pre):
+        one = backend.precompute_flow_info(a, b, {"backend": "HIP", "pov_mode": True, "cut_threshold": 0.0})
+        assert np.array_equal(np.asarray(info["flow"]), np.asarray(one["flow"]))
+        assert tuple(info["pos_center"]) == (w // 2, h - 1) and info["val_pos"] == 0
+    assert pre[0]["cut"] is True and backend.radial_all(pre, [(1.0, 2.0)] * 3, True) == [0.0, 0.0, 0.0]
+    backend.precompute_all(odd[:1], {"backend": "HIP"})
+    with pytest.raises(_capi.FFLError, match="stale"):
+        np.asarray(pre[1]["flow"])
+    assert backend.precompute_all([], params) == []
+    backend.release_contexts()
