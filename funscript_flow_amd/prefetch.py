@@ -203,3 +203,72 @@ def video_to_actions(ctx, capture, params, engine=None, ring_frames=None):
     finally:
         ring.close()
     return postchain.actions_from_scalars(dots, cuts, frame_idx, fps, params)
+
+
+def process_video(video_path, params, log_func, open_capture, make_context, progress_callback=None, cancel_flag=None):
+    """The call shape and outcomes of the reference's process_video (FF:1094-1404) on the HIP path: returns
+    `error_occurred`, writes `<video>.funscript` next to the video, never lets an exception escape (errors are logged as
+    "ERROR: ..." and reported through the return value, FF:1115-1117, FF:1396-1398), skips existing outputs unless
+    params["overwrite"] (FF:1107-1109).  The two things the reference hard-wires are arguments here:
+        open_capture(video_path) -> a cv2.VideoCapture-like object (FF:1114 opens one through VideoReaderCV)
+        make_context(capture)    -> the device Context for the operand size (256x256 in the reference, FF:1057)
+    cancel_flag() is polled per chunk like FF:1146."""
+    import os
+    import time
+    start = time.time()
+    base, _ = os.path.splitext(video_path)
+    output_path = base + ".funscript"
+    if os.path.exists(output_path) and not params.get("overwrite", False):
+        log_func(f"Skipping: output file exists ({output_path})")
+        return False
+    try:
+        log_func(f"Processing video: {video_path}")
+        cap = open_capture(video_path)
+        if hasattr(cap, "isOpened") and not cap.isOpened():
+            raise DecodeError("capture did not open")
+    except Exception as e:  # noqa: BLE001
+        log_func(f"ERROR: Unable to open video at {video_path}: {e}")
+        return True
+    try:
+        total, fps = int(cap.get(CAP_PROP_FRAME_COUNT)), float(cap.get(CAP_PROP_FPS))
+        if total < 1 or fps <= 0:
+            raise DecodeError(f"{total} frames at {fps} fps")
+    except Exception as e:  # noqa: BLE001
+        log_func(f"ERROR: Unable to read video properties: {e}")
+        return True
+    from . import frontend, pipeline
+    step, effective_fps, indices = postchain.sampling(fps, total)
+    log_func(f"FPS: {fps:.2f}; downsampled to ~{effective_fps:.2f} fps; {len(indices)} frames selected.")
+    log_func("Using backend: HIP")
+    error_occurred = False
+    ctx = ring = None
+    try:
+        ctx = make_context(cap)
+        engine = pipeline.PairEngine(ctx, frontend.DecodedUploader(ctx, bool(params.get("vr_mode")), False))
+        ring = PrefetchRing(ctx, cap, indices, int(params.get("batch_size", 3000.0)), 4 * ctx.max_batch + 2)
+        dots, cuts, frame_idx, done = [], [], [], 0
+        for view, fidx in ring.chunks():
+            if cancel_flag and cancel_flag():
+                log_func("User bailed.")
+                return error_occurred
+            d, recs = engine.process_chunk(view, bool(params.get("pov_mode", False)), float(params.get("cut_threshold", 7)))
+            dots += [float(v) for v in d]
+            cuts += [bool(r[4]) for r in recs]
+            frame_idx += fidx
+            done += len(view)
+            if progress_callback:
+                progress_callback(min(100, int(100 * done / max(len(indices), 1))))
+        actions = postchain.actions_from_scalars(dots, cuts, frame_idx, fps, params)
+        log_func(f"Keyframe reduction: {len(actions)} actions computed.")
+        postchain.write_funscript(output_path, actions)
+        log_func(f"Funscript saved: {output_path}")
+    except Exception as e:  # noqa: BLE001
+        log_func(f"ERROR: {e}")
+        error_occurred = True
+    finally:
+        if ring is not None:
+            ring.close()
+        if hasattr(cap, "release"):
+            cap.release()
+    log_func(f"Processing time: {time.time() - start:.2f} seconds")
+    return error_occurred

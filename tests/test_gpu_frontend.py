@@ -121,3 +121,57 @@ def test_video_to_actions_through_the_prefetch_ring():
         want = pipeline.frames_to_actions(eng, [src[i] for i in range(n)], fps, params)
     assert cap.seeks == 0
     assert got == want and len(got) == 48          # 51 sampled frames -> chunks of 20, 20, 11 -> 19 + 19 + 10 pairs
+
+
+def test_process_video_writes_the_funscript(tmp_path):
+    """prefetch.process_video: the reference's process_video call shape (FF:1094-1404) on the HIP path -- logs, progress,
+    `<video>.funscript` written, returns False; the file equals what video_to_actions computes for the same capture."""
+    import json
+    from funscript_flow_amd import pipeline, prefetch
+    from funscript_flow_amd.synth import gray_to_bgr, sine_translate_frames
+    sw, sh, n, fps = 200, 120, 45, 30.0
+    src = gray_to_bgr(sine_translate_frames(n, sw, sh, seed=9, amp=(3.0, 2.0), period=12, zoom=0.04))
+
+    class Cap:
+        def __init__(self):
+            self.pos, self.released = 0, False
+
+        def isOpened(self):
+            return True
+
+        def get(self, prop):
+            return {prefetch.CAP_PROP_FRAME_COUNT: n, prefetch.CAP_PROP_FPS: fps, prefetch.CAP_PROP_FRAME_WIDTH: sw,
+                    prefetch.CAP_PROP_FRAME_HEIGHT: sh}[prop]
+
+        def grab(self):
+            self.pos += 1
+            return self.pos <= n
+
+        def read(self, image=None):
+            if self.pos >= n:
+                return False, None
+            f = src[self.pos].copy()                 # a capture that returns its own array (no decode-into)
+            self.pos += 1
+            return True, f
+
+        def release(self):
+            self.released = True
+
+    params = {"detrend_window": 1.0, "norm_window": 1.0, "batch_size": 30, "keyframe_reduction": True, "overwrite": True}
+    video = str(tmp_path / "clip.mp4")
+    logs, progress, caps = [], [], []
+
+    def open_capture(path):
+        caps.append(Cap())
+        return caps[-1]
+
+    def make_context(cap):
+        return _capi.Context(96, 64, max_batch=4, frame_slots=10, flow_slots=pipeline.min_flow_slots(4))
+
+    assert prefetch.process_video(video, params, logs.append, open_capture, make_context, progress.append) is False
+    assert caps[0].released and progress and progress[-1] == 100
+    assert any(m.startswith("FPS: 30.00; downsampled to ~30.00 fps; 45 frames selected.") for m in logs)
+    got = json.load(open(str(tmp_path / "clip.funscript")))
+    with _capi.Context(96, 64, max_batch=4, frame_slots=10, flow_slots=pipeline.min_flow_slots(4)) as ctx:
+        want = prefetch.video_to_actions(ctx, Cap(), params)
+    assert got == {"version": "1.0", "actions": want} and len(want) >= 3

@@ -182,3 +182,34 @@ def test_released_frames_cannot_be_requested_again():
             view[20]
     finally:
         ring.close()
+
+
+def test_process_video_outcomes_without_a_device(tmp_path):
+    """The reference's process_video contract (FF:1094-1404) for the outcomes that need no device: existing output is
+    skipped unless overwrite, a capture that does not open or has no frames is an error that is LOGGED and RETURNED,
+    never raised; a failure further down (here: no device context) likewise."""
+    logs = []
+    video = str(tmp_path / "clip.mp4")
+    out = str(tmp_path / "clip.funscript")
+    open(out, "w").write("{}")
+    assert prefetch.process_video(video, {"overwrite": False}, logs.append, lambda p: FakeCapture(10), lambda c: None) is False
+    assert logs[-1].startswith("Skipping: output file exists") and open(out).read() == "{}"
+
+    class Closed(FakeCapture):
+        def isOpened(self):
+            return False
+
+    logs.clear()
+    assert prefetch.process_video(video, {"overwrite": True}, logs.append, lambda p: Closed(10), lambda c: None) is True
+    assert any(m.startswith("ERROR: Unable to open video") for m in logs)
+    logs.clear()
+    assert prefetch.process_video(video, {"overwrite": True}, logs.append, lambda p: FakeCapture(0), lambda c: None) is True
+    assert any(m.startswith("ERROR: Unable to read video properties") for m in logs)
+
+    def no_device(cap):
+        raise RuntimeError("no HIP device")
+
+    logs.clear()
+    assert prefetch.process_video(video, {"overwrite": True}, logs.append, lambda p: FakeCapture(20), no_device) is True
+    assert any(m == "ERROR: no HIP device" for m in logs) and logs[-1].startswith("Processing time:")
+    assert open(out).read() == "{}"                     # nothing was written over the old file
