@@ -293,3 +293,21 @@ def test_graph_cache_is_bounded_and_shapes_may_vary_freely():
         _capi.set_option("graph", 1)
         _capi.set_option("lanes", 2)
     assert np.array_equal(np.frombuffer(want[nmax][0], np.float32).reshape(h, w, 2), orc.farneback(fr[nmax - 1], fr[nmax]))
+
+
+def test_largest_baseline_frame_5760x2880_whole():
+    """The largest frame BASELINE names, taken whole (SURVEY App. C "5 whole frame": 16.6 Mpx, 332 MB per 5-plane
+    field, 8.3 GB of algorithmic traffic per pair): one pair bit for bit against the oracle, reductions on the
+    device's own flow, pass 2 -- the 32-bit plane offsets and the largest grids of every kernel."""
+    W, H = 5760, 2880
+    fr = sine_translate_frames(2, W, H, seed=2, amp=(5.0, 3.0))
+    with _capi.Context(W, H, max_batch=1, frame_slots=2, flow_slots=1) as ctx:
+        ctx.submit_pair(0, fr[0], fr[1])
+        rec = ctx.pass1_result(0)
+        flow = ctx.download_flow(0)
+        c = (0.47 * W, 0.55 * H)
+        got = ctx.radial([0], [c], [False], False)[0]
+    assert np.array_equal(flow, orc.farneback(fr[0], fr[1]))
+    _check_reductions_on_own_flow(None, 0, rec, flow)
+    want = float(orc.radial_np(flow, c, False, False))
+    assert abs(got - want) <= 1e-4 * max(abs(want), 1e-6 * W)
