@@ -1199,6 +1199,25 @@ __device__ __forceinline__ void ffl_box_quarter(const double (&d)[18], double (&
     if (Q == 0) out[0] = S[0];  // t = 0: the window is the suffix alone
 }
 
+#ifdef FFL_STAMP
+// Diagnostic build only (profiles/tools/k5_stamps.sh): thread 0 of every workgroup of the level-0 folded launch adds the
+// cycles between consecutive stamp points into LDS counters and leaves them in a device array the host reads back.
+// Shares, not absolute times, are what this build is good for (cdna_hip_programming.md section 7, in-kernel stamps).
+#define FFL_NSTAMP 16
+__device__ unsigned long long g_stamp[64][FFL_NSTAMP];
+extern "C" int ffl_debug_read_stamps(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * 64 * FFL_NSTAMP);
+}
+#define FFL_T(i)                                                              \
+    if (FFL_STAMP_ON && tid == 0) {                                           \
+        const unsigned long long t_ = __builtin_readcyclecounter();          \
+        sStamp[i] += t_ - sStamp[FFL_NSTAMP];                                 \
+        sStamp[FFL_NSTAMP] = t_;                                              \
+    }
+#else
+#define FFL_T(i)
+#endif
+
 static int g_blur_rows = 0;  // 0: automatic (ffl_blur_rows_per_wg)
 void ffl_set_blur_rows(int n) { g_blur_rows = n; }
 
@@ -1225,6 +1244,14 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
     constexpr int GC = FIRST ? FFL_K5_GROUP_FIRST : FFL_K5_GROUP, NG = (5 + GC - 1) / GC;  // channels per LDS pass, passes
     __shared__ double2 sS2[GC][TH][LW2];
     const int tid = threadIdx.x;
+#ifdef FFL_STAMP
+    __shared__ unsigned long long sStamp[FFL_NSTAMP + 1];
+    const bool FFL_STAMP_ON = FIRST == 1 && w >= 1024;
+    if (FFL_STAMP_ON && tid == 0) {
+        for (int i = 0; i < FFL_NSTAMP; i++) sStamp[i] = 0;
+        sStamp[FFL_NSTAMP] = __builtin_readcyclecounter();
+    }
+#endif
     // A workgroup walks down `nrb` vertically adjacent tiles (a column strip of 64 x 16*nrb pixels) and
     // keeps the 14 rows two consecutive tiles share in registers: phase V then loads 16 new rows per tile
     // instead of 30 -- its halo re-reads (30 rows for 16 outputs) were the kernel's largest single cost.
@@ -1323,14 +1350,18 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
                 }
                 __syncthreads();
             }
+            FFL_T(0)   // loop overhead / previous tile's end barrier already counted
             phase_u(y0, NCARRY, TH);
+            FFL_T(1)   // phase U work
             __syncthreads();
+            FFL_T(2)   // wait after U
         }
 #pragma unroll
         for (int g = 0; g < NG; g++) {
             const int c0 = g * GC, nc = min(GC, 5 - c0);
             // ---- phase V: column sums over 15 rows, one (channel, tile column) per lane ------------
             if (g) __syncthreads();  // the previous group's sums have been consumed
+            FFL_T(3)   // (g = 1) wait for the other waves' phase H
             const bool vlane = tid < nc * LW;
             float v[LH];
             if (vlane) {
@@ -1373,7 +1404,9 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
 #pragma unroll
                 for (int j = 0; j < TH; j++) sS[(vcc * TH + j) * (2 * LW2) + pos] = o[j];
             }
+            FFL_T(4)   // phase V work
             __syncthreads();
+            FFL_T(5)   // wait after V
             // ---- phase H: 4 window sums per lane from 18 column sums (9 x ds_read_b128) -------------
 #pragma unroll
             for (int cc = 0; cc < GC; cc++) {
@@ -1399,11 +1432,13 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
             }
         }
 
+        FFL_T(6)   // phase H work (both groups)
         // ---- solve (+ fused UpdateMatrices) -----------------------------------------------------------
         // The solved displacements are transposed through LDS (aliasing the column-sum buffer) so that
         // the global phase below runs with lanes along x: 512-B flow rows per wave store, and the
         // bilinear gathers of R1 by neighbouring lanes fall into neighbouring addresses.
         __syncthreads();  // every lane has finished reading the column sums
+        FFL_T(7)   // wait before the solve
         {
             float2 f[PX];
 #pragma unroll
@@ -1417,7 +1452,9 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
             sF4[(ty * FP + lx0) / 2] = make_float4(f[0].x, f[0].y, f[1].x, f[1].y);
             sF4[(ty * FP + lx0) / 2 + 1] = make_float4(f[2].x, f[2].y, f[3].x, f[3].y);
         }
+        FFL_T(8)   // solve work
         __syncthreads();
+        FFL_T(9)   // wait after the solve
         // two adjacent pixels per lane: 16-byte flow stores, 8-byte R0 loads / M stores / R1 gathers --
         // half the vector-memory instructions of a pixel-per-lane mapping.  32 lanes span the tile row,
         // the workgroup covers 8 rows per pass.
@@ -1448,8 +1485,14 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
                 if (UPDATE) ffl_um_pair(R0, R1, plane, w, h, x, y, f0, f1, second, in, Mo);
             }
         }
+        FFL_T(10)  // store + fused UpdateMatrices (issue + waits for its own loads)
         __syncthreads();  // sF has been read: the next tile's column sums may overwrite it
+        FFL_T(11)  // wait at the end of the tile
     }
+#ifdef FFL_STAMP
+    if (FFL_STAMP_ON && tid == 0)
+        for (int i = 0; i < FFL_NSTAMP; i++) g_stamp[blockIdx.x & 63][i] = sStamp[i];
+#endif
 }
 
 // tiles a workgroup walks down: as many as still leave the device about four rounds of workgroups
