@@ -187,6 +187,24 @@ __device__ __forceinline__ bool ffl_tile_coord(int tiles_x, int tiles_y, int nB,
     return true;
 }
 
+// A pointer read from a device-resident table (PairTab / RadialTab) is a generic pointer to the compiler: it
+// emits flat_load with per-lane 64-bit address arithmetic and waits on two counters.  Every such pointer is a
+// hipMalloc'ed buffer, so its accesses go through these helpers, which name the global address space:
+// global_load, saddr form when the base is wave-uniform.  Vectors need 4-byte alignment only.
+// Used by the post kernels (k_pass1 -5 %, k_radial -2 %).  NOT by k_blur_solve / k_update_matrices: there the same
+// change made the folded launch 3 % slower (1826 -> 1880 us, same-box A/B) -- their coarse-flow gathers stay flat.
+#define FFL_GLOBAL __attribute__((address_space(1)))
+typedef float ffl_v2f __attribute__((ext_vector_type(2), aligned(4)));
+typedef float ffl_v4f __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float2 ffl_gload2(const void *base, size_t byte_off) {
+    const ffl_v2f v = *(const FFL_GLOBAL ffl_v2f *)((const char *)base + byte_off);
+    return make_float2(v.x, v.y);
+}
+__device__ __forceinline__ float4 ffl_gload4(const void *base, size_t byte_off) {
+    const ffl_v4f v = *(const FFL_GLOBAL ffl_v4f *)((const char *)base + byte_off);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // 8- and 16-byte vectors that are only 4-byte aligned: gfx950 global loads/stores of dwordx2/x4 need
 // dword alignment only.  Wider accesses pay where they cut the number of lane requests to the vector L1
 // (byte taps of the pyramid fetched as words: 54 -> 22 us; one 16-byte R1 load serving two pixels instead

@@ -30,8 +30,8 @@ __device__ __forceinline__ float ffl_grad(float lo, float hi, int idx, int n) {
 __device__ __forceinline__ float ffl_div_at(const float2 *__restrict__ flow, int w, int h, int x, int y) {
     int ya = y == 0 ? 0 : y - 1, yb = y == h - 1 ? h - 1 : y + 1;
     int xa = x == 0 ? 0 : x - 1, xb = x == w - 1 ? w - 1 : x + 1;
-    float du = ffl_grad(flow[(size_t)ya * w + x].x, flow[(size_t)yb * w + x].x, y, h);   // d(u)/dy
-    float dv = ffl_grad(flow[(size_t)y * w + xa].y, flow[(size_t)y * w + xb].y, x, w);   // d(v)/dx
+    float du = ffl_grad(ffl_gload2(flow, 8u * ((size_t)ya * w + x)).x, ffl_gload2(flow, 8u * ((size_t)yb * w + x)).x, y, h);   // d(u)/dy
+    float dv = ffl_grad(ffl_gload2(flow, 8u * ((size_t)y * w + xa)).y, ffl_gload2(flow, 8u * ((size_t)y * w + xb)).y, x, w);   // d(v)/dx
     return du + dv;
 }
 
@@ -40,7 +40,7 @@ __device__ __forceinline__ void ffl_load_pair(const float2 *__restrict__ flow, i
                                               float2 &p1) {
     const int yc = min(max(y, 0), h - 1);
     const int xa = min(max(x, 0), w - 2);  // pair start inside the row
-    const ffl_f4u t = *reinterpret_cast<const ffl_f4u *>(flow + (size_t)yc * w + xa);
+    const float4 t = ffl_gload4(flow, 8u * ((unsigned)yc * (unsigned)w + (unsigned)xa))  /* < 2^32: ffl_create */;
     const float2 A = make_float2(t.x, t.y), B = make_float2(t.z, t.w);
     p0 = (min(max(x, 0), w - 1) == xa) ? A : B;
     p1 = (min(max(x + 1, 0), w - 1) == xa) ? A : B;
