@@ -262,22 +262,34 @@ __device__ __forceinline__ void ffl_um_gather(const UmLoc &L, const float *__res
     }
 }
 
+// BRANCHY: the inside / outside cases as a divergent branch (the standalone kernel and the fused update of k_blur_solve:
+// the select form made k_blur_solve<true,0> 4 % slower) or as selects (the pipelined phase U: a divergent branch around
+// loaded values makes the compiler wait for every outstanding load, the prefetched ones included).
+template <bool BRANCHY = true>
 __device__ __forceinline__ void ffl_um_finish(const float (&r0)[5], const float (&b)[5], bool inside, int w, int h, int x,
                                               int y, float dx, float dy, float (&out)[5]) {
     // border[5] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} as selects (no runtime-indexed array)
 #define FFL_BORDER(i) ((i) < 2 ? 0.14f : 0.4472f)
     float r2, r3, r4, r5, r6;
-    if (inside) {
-        r2 = b[0];
-        r3 = b[1];
-        r4 = (r0[2] + b[2]) * 0.5f;
-        r5 = (r0[3] + b[3]) * 0.5f;
-        r6 = (r0[4] + b[4]) * 0.25f;
+    if (BRANCHY) {
+        if (inside) {
+            r2 = b[0];
+            r3 = b[1];
+            r4 = (r0[2] + b[2]) * 0.5f;
+            r5 = (r0[3] + b[3]) * 0.5f;
+            r6 = (r0[4] + b[4]) * 0.25f;
+        } else {
+            r2 = r3 = 0.f;
+            r4 = r0[2];
+            r5 = r0[3];
+            r6 = r0[4] * 0.5f;
+        }
     } else {
-        r2 = r3 = 0.f;
-        r4 = r0[2];
-        r5 = r0[3];
-        r6 = r0[4] * 0.5f;
+        r2 = inside ? b[0] : 0.f;
+        r3 = inside ? b[1] : 0.f;
+        r4 = inside ? (r0[2] + b[2]) * 0.5f : r0[2];
+        r5 = inside ? (r0[3] + b[3]) * 0.5f : r0[3];
+        r6 = inside ? (r0[4] + b[4]) * 0.25f : r0[4] * 0.5f;
     }
     r2 = (r0[0] - r2) * 0.5f;
     r3 = (r0[1] - r3) * 0.5f;

@@ -1286,47 +1286,92 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
     float *sM012 = reinterpret_cast<float *>(&sS2[0][0][0]);                     // channels 0 .. GC-1: [GC][TH][UP]
     static_assert(GC * TH * UP * 4 <= (int)sizeof(sS2), "the first group's staged rows must fit the column sums");
     const float2 *prevf = reinterpret_cast<const float2 *>(pt->flow[min(level + 1, FFL_MAX_LEVELS - 1)][b]);
-    // M of the tile rows whose phase-V index is jbase .. jbase+nrows-1 (image rows y0-7+jbase ..), all 78 columns
-    // one item = two adjacent tile columns (2p, 2p+1) of one row: 39 x nrows items, two pixels per lane like the
-    // standalone kernel (8-byte R0 loads, shared 16-byte R1 loads); columns clamped into the image that fall on
-    // the same pixel are computed once
-    auto upsampled = [&](int gx, int gy) {  // K3: resize(prevFlow, (w, h), INTER_LINEAR) * 2, as in k_update_matrices<1>
-        int xa0, xa1, ya0, ya1;
+    // phase U: M of the tile rows whose phase-V index is jbase .. jbase+nrows-1 (image rows y0-7+jbase ..), all 78
+    // columns; the level's initial flow is the x2 upsample of the coarser level's (K3: resize(prevFlow, (w, h),
+    // INTER_LINEAR) * 2, as in k_update_matrices<1>), formed per pixel and never stored.
+    // Software-pipelined phase U, one pixel per lane.  An item costs two DEPENDENT memory round trips (the coarse
+    // flow's corners, then R1 at the displaced position); with 3 waves per SIMD the waves sat in s_waitcnt half of
+    // their cycles.  The NEXT item's flow corners are requested right after the current item's gathers, so that
+    // round trip runs under the gathers' wait and the item's arithmetic (level-0 launch 1850 -> 1790 us).  One pixel
+    // per lane (not the pair of the standalone kernel) keeps the two items in flight within the 168-register budget
+    // of 3 waves per SIMD: the pair version of the same pipeline spilled 55 registers and ran at 2720 us; one stage
+    // deeper (the next item's R1 gathers in flight as well) spilled too, 1900 us.
+    struct UStageA {
         float a1, b1;
-        ffl_resize_coord(gx, pw, usx, xa0, xa1, a1);
-        ffl_resize_coord(gy, ph, usy, ya0, ya1, b1);
-        const float a0 = 1.f - a1, b0 = 1.f - b1;
-        const float *pf = reinterpret_cast<const float *>(prevf);  // wave-uniform base + 32-bit offsets (ffl_at)
-        const unsigned r0o = (unsigned)ya0 * (unsigned)pw, r1o = (unsigned)ya1 * (unsigned)pw;
-        const float2 p00 = *ffl_at<float2>(pf, 2u * (r0o + xa0)), p01 = *ffl_at<float2>(pf, 2u * (r0o + xa1)),
-                     p10 = *ffl_at<float2>(pf, 2u * (r1o + xa0)), p11 = *ffl_at<float2>(pf, 2u * (r1o + xa1));
-        float2 f;
-        float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
-        f.x = (t0 * b0 + t1 * b1) * 2.0f;
-        t0 = p00.y * a0 + p01.y * a1;
-        t1 = p10.y * a0 + p11.y * a1;
-        f.y = (t0 * b0 + t1 * b1) * 2.0f;
-        return f;
+        float2 p[4];
     };
     auto phase_u = [&](int y0, int jbase, int nrows) {
-        constexpr int NP = LW / 2;
-#pragma unroll 1
-        for (int i = tid; i < NP * nrows; i += 256) {
-            const int r = i / NP, tx = 2 * (i - r * NP);
-            const int gy = min(max(y0 - FFL_WIN_R + jbase + r, 0), h - 1);
-            const int xa = min(max(x0 + tx - FFL_WIN_R, 0), w - 1), xb = min(max(x0 + tx + 1 - FFL_WIN_R, 0), w - 1);
-            const bool second = xb == xa + 1;
-            float2 f0 = make_float2(0.f, 0.f), f1 = make_float2(0.f, 0.f);
+        const int N = LW * nrows;
+        auto coords = [&](int i, int &r, int &tx, int &gx, int &gy) {
+            r = i / LW;
+            tx = i - r * LW;
+            gy = min(max(y0 - FFL_WIN_R + jbase + r, 0), h - 1);
+            gx = min(max(x0 + tx - FFL_WIN_R, 0), w - 1);
+        };
+        auto issue = [&](int i) {
+            UStageA A;
+            int r, tx, gx, gy;
+            coords(i, r, tx, gx, gy);
             if (FIRST == 1) {
-                f0 = upsampled(xa, gy);
-                f1 = upsampled(xb, gy);
+                int xa0, xa1, ya0, ya1;
+                ffl_resize_coord(gx, pw, usx, xa0, xa1, A.a1);
+                ffl_resize_coord(gy, ph, usy, ya0, ya1, A.b1);
+                const float *pf = reinterpret_cast<const float *>(prevf);
+                const unsigned r0o = (unsigned)ya0 * (unsigned)pw, r1o = (unsigned)ya1 * (unsigned)pw;
+                // global-address loads (ffl_gload2): behind a FLAT load the compiler can only wait for "everything"
+                A.p[0] = ffl_gload2(pf, 8u * (r0o + xa0)); A.p[1] = ffl_gload2(pf, 8u * (r0o + xa1));
+                A.p[2] = ffl_gload2(pf, 8u * (r1o + xa0)); A.p[3] = ffl_gload2(pf, 8u * (r1o + xa1));
             }
-            float ma[5], mb[5];
-            ffl_um_pair_values(R0, R1, plane, w, h, xa, gy, f0, f1, second, ma, mb);
+            return A;
+        };
+        int i = tid;
+        if (i >= N) return;
+        UStageA A = issue(i);
+#pragma unroll 1
+        for (;;) {
+            int r, tx, gx, gy;
+            coords(i, r, tx, gx, gy);
+            const int inext = i + 256;
+            const bool more = inext < N;
+            float2 f = make_float2(0.f, 0.f);
+            if (FIRST == 1) {
+                const float a0 = 1.f - A.a1, b0 = 1.f - A.b1;
+                float t0 = A.p[0].x * a0 + A.p[1].x * A.a1, t1 = A.p[2].x * a0 + A.p[3].x * A.a1;
+                f.x = (t0 * b0 + t1 * A.b1) * 2.0f;
+                t0 = A.p[0].y * a0 + A.p[1].y * A.a1;
+                t1 = A.p[2].y * a0 + A.p[3].y * A.a1;
+                f.y = (t0 * b0 + t1 * A.b1) * 2.0f;
+            }
+            float r0[5];
+            {
+                const unsigned o = (unsigned)gy * (unsigned)w + (unsigned)gx;
 #pragma unroll
-            for (int c = 0; c < GC; c++) *reinterpret_cast<float2 *>(&sM012[(c * TH + r) * UP + tx]) = make_float2(ma[c], mb[c]);
+                for (int c = 0; c < 5; c++) r0[c] = *ffl_at<float>(R0 + c * plane, o);
+            }
+            const UmLoc L = ffl_um_locate(w, h, gx, gy, f.x, f.y);
+            // branch-free gather: lanes that land outside read the (valid) corner of pixel (0, 0) and drop it
+            const unsigned o1 = L.inside ? (unsigned)L.y1 * (unsigned)w + (unsigned)L.x1 : 0u;
+            ffl_f2u t[5], u[5];
 #pragma unroll
-            for (int c = GC; c < 5; c++) *reinterpret_cast<float2 *>(&sM34[c - GC][r][tx]) = make_float2(ma[c], mb[c]);
+            for (int c = 0; c < 5; c++) {
+                t[c] = *ffl_at<ffl_f2u>(R1 + c * plane, o1);
+                u[c] = *ffl_at<ffl_f2u>(R1 + c * plane, o1 + (unsigned)w);
+            }
+            // unconditional (a lane without a next item re-requests its own corners, cache hits): a fixed number of
+            // loads behind the gathers lets the wait below be "all but the last 4", not "all"
+            const UStageA Anext = issue(more ? inext : i);
+            float b[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) b[c] = L.a00 * t[c].x + L.a01 * t[c].y + L.a10 * u[c].x + L.a11 * u[c].y;
+            float m[5];
+            ffl_um_finish<false>(r0, b, L.inside, w, h, gx, gy, f.x, f.y, m);
+#pragma unroll
+            for (int c = 0; c < GC; c++) sM012[(c * TH + r) * UP + tx] = m[c];
+#pragma unroll
+            for (int c = GC; c < 5; c++) sM34[c - GC][r][tx] = m[c];
+            if (!more) break;
+            A = Anext;
+            i = inext;
         }
     };
 
@@ -1455,34 +1500,83 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
         FFL_T(8)   // solve work
         __syncthreads();
         FFL_T(9)   // wait after the solve
-        // two adjacent pixels per lane: 16-byte flow stores, 8-byte R0 loads / M stores / R1 gathers --
-        // half the vector-memory instructions of a pixel-per-lane mapping.  32 lanes span the tile row,
-        // the workgroup covers 8 rows per pass.
-        const int lx = 2 * (tid & 31), x = x0 + lx;
-        if (x < w) {
-            const bool second = x + 1 < w;
-            // branch-free over the lane's rows (clamped loads, predicated stores): all gathers in flight
-#pragma unroll
-            for (int k = 0; k < TH / 8; k++) {
-                const int ly = (tid >> 5) + 8 * k;
-                const bool in = y0 + ly < h;
+        if (UPDATE) {
+            // One pixel per lane, lanes along x (a wave = one 64-pixel tile row, wave q takes rows q, q+4, q+8, q+12),
+            // double-buffered: the R0 values and R1 corners of the lane's next row are requested before the current
+            // row's arithmetic, so only the first of the four round trips is exposed.  No divergent branch touches a
+            // loaded value (ffl_um_finish<false>), so the waits are "all but the newest 15", never "all".
+            struct UmRow {
+                float2 f;
+                float a00, a01, a10, a11;
+                bool inside;
+                float r0[5];
+                ffl_f2u t[5], u[5];
+            };
+            const int lx = tid & 63, x = min(x0 + lx, w - 1);
+            const bool xin = x0 + lx < w;
+            const float2 *sF2 = reinterpret_cast<const float2 *>(sF4);
+            auto issue = [&](int k) {
+                UmRow S;
+                const int ly = (tid >> 6) + 4 * k;
                 const int y = min(y0 + ly, h - 1);
-                const float4 ff = sF4[(ly * FP + lx) >> 1];
-                const float2 f0 = make_float2(ff.x, ff.y), f1 = make_float2(ff.z, ff.w);
-                const size_t o = (size_t)y * w + x;
-                // UPDATE launches: the displacement is consumed by the fused UpdateMatrices below and the next
-                // iteration reads only M -- the field itself is dead until the level's last iteration (8 B per
-                // pixel and launch not written; the debug capture asks for it)
-                if (in && (!UPDATE || store_flow)) {
+                S.f = sF2[ly * FP + lx];
+                const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
+#pragma unroll
+                for (int c = 0; c < 5; c++) S.r0[c] = *ffl_at<float>(R0 + c * plane, o);
+                const UmLoc L = ffl_um_locate(w, h, x, y, S.f.x, S.f.y);
+                S.a00 = L.a00; S.a01 = L.a01; S.a10 = L.a10; S.a11 = L.a11; S.inside = L.inside;
+                const unsigned o1 = L.inside ? (unsigned)L.y1 * (unsigned)w + (unsigned)L.x1 : 0u;
+#pragma unroll
+                for (int c = 0; c < 5; c++) {
+                    S.t[c] = *ffl_at<ffl_f2u>(R1 + c * plane, o1);
+                    S.u[c] = *ffl_at<ffl_f2u>(R1 + c * plane, o1 + (unsigned)w);
+                }
+                return S;
+            };
+            UmRow cur = issue(0);
+#pragma unroll
+            for (int k = 0; k < TH / 4; k++) {
+                UmRow nxt;
+                if (k + 1 < TH / 4) nxt = issue(k + 1);
+                const int ly = (tid >> 6) + 4 * k;
+                const bool in = xin && y0 + ly < h;
+                const int y = min(y0 + ly, h - 1);
+                const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
+                // the displacement is consumed by the UpdateMatrices right here and the next iteration reads only M: the
+                // field itself is dead until the level's last iteration (8 B per pixel and launch not written; the debug
+                // capture asks for it)
+                if (in && store_flow) *reinterpret_cast<float2 *>(ffl_at<float>(reinterpret_cast<float *>(flow), 2u * o)) = cur.f;
+                float bb[5];
+#pragma unroll
+                for (int c = 0; c < 5; c++) bb[c] = cur.a00 * cur.t[c].x + cur.a01 * cur.t[c].y + cur.a10 * cur.u[c].x + cur.a11 * cur.u[c].y;
+                float m[5];
+                ffl_um_finish<false>(cur.r0, bb, cur.inside, w, h, x, y, cur.f.x, cur.f.y, m);
+                if (in) {
+#pragma unroll
+                    for (int c = 0; c < 5; c++) *ffl_at<float>(Mo + c * plane, o) = m[c];
+                }
+                if (k + 1 < TH / 4) cur = nxt;
+            }
+        } else {
+            // the level's last iteration: only the field is written -- two adjacent pixels per lane, 16-byte stores
+            // (512-B rows per wave), the workgroup covers 8 rows per pass
+            const int lx = 2 * (tid & 31), x = x0 + lx;
+            if (x < w) {
+                const bool second = x + 1 < w;
+#pragma unroll
+                for (int k = 0; k < TH / 8; k++) {
+                    const int ly = (tid >> 5) + 8 * k;
+                    if (y0 + ly >= h) continue;
+                    const float4 ff = sF4[(ly * FP + lx) >> 1];
+                    const size_t o = (size_t)(y0 + ly) * w + x;
                     if (second) {
                         ffl_f4u t;
                         t.x = ff.x; t.y = ff.y; t.z = ff.z; t.w = ff.w;
                         *reinterpret_cast<ffl_f4u *>(flow + o) = t;
                     } else {
-                        flow[o] = f0;
+                        flow[o] = make_float2(ff.x, ff.y);
                     }
                 }
-                if (UPDATE) ffl_um_pair(R0, R1, plane, w, h, x, y, f0, f1, second, in, Mo);
             }
         }
         FFL_T(10)  // store + fused UpdateMatrices (issue + waits for its own loads)
