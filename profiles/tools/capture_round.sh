@@ -7,14 +7,15 @@ TAG=${1:-cap}
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 O=gpurun_out
-python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o s -- python3 bench.py --no-cpu-baseline --no-extras > $O/${TAG}_bench_under_rocprof.json 2>/dev/null
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_F -o f -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_W -o w -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
 cp profiles/traffic.json /tmp/traffic_prev.json
-BATCH=$(python -c "import json; print(json.load(open('$O/${TAG}_bench.json'))['config']['pairs_per_step'])")
+BATCH=$(python -c "import json; print(json.load(open('$O/${TAG}_bench_under_rocprof.json'))['config']['pairs_per_step'])")
 python profiles/make_traffic.py $O/${TAG}_F/f_counter_collection.csv $O/${TAG}_W/w_counter_collection.csv k_blur_solve 1920x1080 $BATCH $TAG
 cp profiles/traffic.json $O/${TAG}_traffic.json
+# the bench line last, so that it already carries this capture's traffic (profiles/traffic.json, same kernel signature)
+python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python profiles/summarize_trace.py $O/${TAG}_stats/s_kernel_trace.csv > $O/${TAG}_kernel_trace_by_grid.txt
 cp $O/${TAG}_stats/s_kernel_stats.csv $O/${TAG}_kernel_stats.csv
 (python profiles/summarize_pmc.py $O/${TAG}_F/f_counter_collection.csv k_; python profiles/summarize_pmc.py $O/${TAG}_W/w_counter_collection.csv k_) > $O/${TAG}_pmc_fetch_write.txt

@@ -34,6 +34,17 @@ for line in open(os.path.join(P, f"{tag}_kernel_trace_by_grid.txt")):
         grid[(m.group(1).strip(), int(m.group(2)))] = float(m.group(4))
 l0 = max(g for (k, g) in grid if k.startswith("k_blur_solve<true, 1>"))
 tj = json.load(open(os.path.join(P, "traffic.json")))
+pmc = {}
+for line in open(os.path.join(P, f"{tag}_pmc_fetch_write.txt")):
+    m = re.match(r"(\S.*?)\s+(\d+)\s+(FETCH_SIZE|WRITE_SIZE)=([\d.e+]+)", line)
+    if m:
+        pmc[(m.group(1).strip(), int(m.group(2)), m.group(3))] = float(m.group(4))
+
+
+def real_gb(kernel):   # per launch: FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, KiB
+    return (2 * pmc[(kernel, l0, "FETCH_SIZE")] + pmc[(kernel, l0, "WRITE_SIZE")]) * 1024 / 1e9
+
+
 s256 = b["small_image"]
 cpu = b["cpu_baseline"]
 vals = {
@@ -44,6 +55,11 @@ vals = {
     "FRACM": f"{(r.get('frac_measured') or tj['hbm_bytes_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e9 / 8000.0):.3f}",
     "L0A": f"{grid[('k_blur_solve<true, 1>', l0)]:.0f}", "L0B": f"{grid[('k_blur_solve<true, 0>', l0)]:.0f}",
     "L0C": f"{grid[('k_blur_solve<false, 0>', l0)]:.0f}",
+    "L0A_GB": f"{real_gb('k_blur_solve<true, 1>'):.1f}", "L0B_GB": f"{real_gb('k_blur_solve<true, 0>'):.1f}",
+    "L0C_GB": f"{real_gb('k_blur_solve<false, 0>'):.1f}",
+    "L0A_TB": f"{real_gb('k_blur_solve<true, 1>') / grid[('k_blur_solve<true, 1>', l0)] * 1e3:.1f}",
+    "L0B_TB": f"{real_gb('k_blur_solve<true, 0>') / grid[('k_blur_solve<true, 0>', l0)] * 1e3:.1f}",
+    "L0C_TB": f"{real_gb('k_blur_solve<false, 0>') / grid[('k_blur_solve<false, 0>', l0)] * 1e3:.1f}",
     "KC_BS": f"{kc['k_blur_solve']['ms_per_step']:.2f}", "KC_PE": f"{kc['k_polyexp']['ms_per_step']:.2f}",
     "KC_PY": f"{kc['k_pyr_level']['ms_per_step']:.2f}", "KC_P1": f"{kc['k_pass1']['ms_per_step']:.2f}",
     "KC_UM": f"{kc['k_update_matrices']['ms_per_step']:.2f}", "KC_RAD": f"{kc['k_radial']['ms_per_step']:.2f}",
