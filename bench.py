@@ -218,7 +218,27 @@ def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None):
             "h2d_GBps": n / dt * W * H * (3 if bgr else 1) / 1e9, "pairs_per_batch": B}
 
 
+_REAL_STDOUT = None
+
+
+def _quiet_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries write there too (gloo prints a connection banner per
+    process group, from C++): point file descriptor 1 at stderr for the whole run and keep the real stdout for the line."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+
+
+def _emit(line):
+    out = _REAL_STDOUT or sys.stdout
+    out.write(line + "\n")
+    out.flush()
+
+
 def main():
+    _quiet_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -436,7 +456,7 @@ def main():
                                    "sample": f"{npairs} pairs of the same {W}x{H} stream, one pair per worker thread, "
                                              f"{threads} threads = os.cpu_count() as the reference's Pool (FF:1190), "
                                              f"C oracle (Farneback + argmax + mean + radial), {cdt:.1f} s wall"}
-        print(json.dumps(out))
+        _emit(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -311,3 +311,21 @@ def test_largest_baseline_frame_5760x2880_whole():
     _check_reductions_on_own_flow(None, 0, rec, flow)
     want = float(orc.radial_np(flow, c, False, False))
     assert abs(got - want) <= 1e-4 * max(abs(want), 1e-6 * W)
+
+
+def test_bench_prints_exactly_one_json_line():
+    """the driver's contract: stdout of bench.py is ONE JSON line (native libraries' chatter goes to stderr)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-extras",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.split("\n") if l.strip()]
+    assert len(lines) == 1, r.stdout[:2000]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "checked"):
+        assert k in d, k
+    assert d["steps"] == 2 and d["n_gpus"] == 1 and d["checked"] is True
