@@ -26,6 +26,9 @@
  *     one -- an exact-quadratic pair I1(x) = I0(x - d), for which PolyExp -> UpdateMatrices -> Blur+solve must
  *     return d * det / (det + 1e-3) at every interior pixel after ONE iteration (signs, channel order, the
  *     0.5 / 0.25 factors, the M layout, the 1/225 scale and the solve's output order all enter that number).
+ *     A second restatement written independently from SURVEY Appendix A (tests/np_farneback.py, whole-array numpy)
+ *     agrees with this file stage by stage to 1 ulp and on the final flow to 1.1e-5 px: that guards the
+ *     transcription, not the appendix -- against cv2 itself the parity remains unpinned.
  *
  * Arithmetic conventions (these DEFINE the oracle; the HIP kernels follow them op for op):
  *   - compile with -ffp-contract=off: no FMA contraction anywhere;

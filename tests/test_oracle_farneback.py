@@ -237,3 +237,33 @@ def test_border_rules_reflect101_vs_replicate():
     assert np.allclose(R[1][20, 8:-8], 1.0, atol=1e-5)
     b2_edge = sum(float(xg[k]) * (k - 0) for k in range(1, 6))            # row(p) - row(m) with m clamped to column 0
     assert abs(R[1][20, 0] - b2_edge * ig[0]) < 1e-5
+
+
+@pytest.mark.parametrize("w,h,seed", [(96, 80, 3), (160, 128, 4), (320, 256, 5), (131, 97, 6)])
+def test_second_restatement_agrees(w, h, seed):
+    """The C oracle against tests/np_farneback.py, an independent whole-array numpy transcription of SURVEY Appendix A
+    (written from the appendix, not from the C file): every stage and the final flow, on 2-, 3- and 4-scale sizes and
+    an odd size.  Element-wise float stages must agree to the last bit or an ulp; the box filter sums in another
+    order (double), so the flow gets an absolute tolerance of 2e-5 px.  Parity with cv2 itself stays unpinned."""
+    import np_farneback as npf
+    fr = sine_translate_frames(2, w, h, seed=seed, amp=(2.5, 1.5), period=5, zoom=0.02)
+    # stages first (a failure then names the stage): every pyramid level, PolyExp, UpdateMatrices, blur + solve
+    nl = orc.num_levels(w, h)
+    for k in range(nl + 1):
+        lw, lh, sigma, ksize = orc.level_params(w, h, k)
+        I_np = npf.resize_linear(npf.gaussian_blur(fr[0].astype(np.float32), int(ksize), float(sigma)), int(lw), int(lh))
+        assert np.max(np.abs(orc.pyr_level(fr[0], k) - I_np)) <= 2e-4, ("pyramid level", k)
+    I0, I1 = orc.pyr_level(fr[0], 0), orc.pyr_level(fr[1], 0)
+    R0c, R1c = orc.polyexp(I0), orc.polyexp(I1)                       # (5, h, w)
+    R0n, R1n = npf.polyexp(I0), npf.polyexp(I1)                       # (h, w, 5)
+    assert np.max(np.abs(np.moveaxis(R0c, 0, -1) - R0n)) <= 1e-5 * max(1.0, float(np.max(np.abs(R0n)))), "polyexp"
+    rng = np.random.default_rng(seed)
+    flow = rng.uniform(-3, 3, (h, w, 2)).astype(np.float32)
+    Mn = npf.update_matrices(R0n, R1n, flow)
+    Mc = orc.update_matrices(R0c, R1c, flow)
+    Mc = np.moveaxis(Mc, 0, -1) if Mc.shape[0] == 5 else Mc
+    assert np.max(np.abs(Mc - Mn)) <= 1e-5 * max(1.0, float(np.max(np.abs(Mn)))), "update_matrices"
+    want = npf.farneback(fr[0], fr[1])
+    got = orc.farneback(fr[0], fr[1])
+    assert got.shape == want.shape == (h, w, 2)
+    assert float(np.max(np.abs(got - want))) <= 2e-5, float(np.max(np.abs(got - want)))
