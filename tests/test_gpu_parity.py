@@ -68,10 +68,13 @@ def test_pair_end_to_end(w, h, seed):
             assert ctx.radial([j], [c], [True], False)[0] == 0.0
 
 
+@pytest.mark.parametrize("fuse", [10000, 1])
 @pytest.mark.parametrize("kind", ["constant", "noise", "checker", "big_shift"])
-def test_degenerate_and_hostile_inputs(kind):
+def test_degenerate_and_hostile_inputs(kind, fuse):
     """Flat frames (all-zero M, denormal-range sums), uncorrelated noise (large erratic flow, many
-    out-of-bounds warps), a 1-px checkerboard and a 40-px jump (coarse levels dominate)."""
+    out-of-bounds warps), a 1-px checkerboard and a 40-px jump (coarse levels dominate) -- on the separate-launch path
+    and (fuse = 1) on the folded first iteration, whose pipelined phase U gathers branch-free: lanes that land outside
+    the image read pixel (0, 0) and must drop it."""
     w, h = 192, 136
     rng = np.random.default_rng(42)
     if kind == "constant":
@@ -85,10 +88,14 @@ def test_degenerate_and_hostile_inputs(kind):
     else:
         big = sine_translate_frames(1, w + 80, h, seed=6)[0]
         a, b = np.ascontiguousarray(big[:, 40:40 + w]), np.ascontiguousarray(big[:, :w])
-    with _capi.Context(w, h, max_batch=1) as ctx:
-        ctx.submit_pair(0, a, b)
-        flow = ctx.download_flow(0)
-        x, y, v, mm, cut = ctx.pass1_result(0)
+    try:
+        _capi.set_option("fuse_first", fuse)
+        with _capi.Context(w, h, max_batch=1) as ctx:
+            ctx.submit_pair(0, a, b)
+            flow = ctx.download_flow(0)
+            x, y, v, mm, cut = ctx.pass1_result(0)
+    finally:
+        _capi.set_option("fuse_first", 10000)
     ref = orc.farneback(a, b)
     assert np.array_equal(flow, ref) and np.isfinite(flow).all()
     ox, oy, ov = orc.max_divergence_np(ref)
