@@ -225,6 +225,16 @@ __device__ __forceinline__ T *ffl_at(float *base, unsigned idx) {
     return reinterpret_cast<T *>(reinterpret_cast<char *>(base) + idx * 4u);
 }
 
+// The two horizontally adjacent corners of a bilinear gather / one coarse-flow vector.  A wave64 global load of 8 bytes
+// per lane occupies the CU's vector-memory path for ~19 cycles, one of 4 bytes for ~6 and one of 16 bytes for ~17
+// (cache-resident data, profiles/tools/micro/vmem_issue.hip): two dword loads are cheaper than one dwordx2.
+__device__ __forceinline__ ffl_f2u ffl_ld_corner(const float *plane_base, unsigned idx) {
+    ffl_f2u v;
+    v.x = *ffl_at<float>(plane_base, idx);
+    v.y = *ffl_at<float>(plane_base, idx + 1u);
+    return v;
+}
+
 // update-matrices body shared by the standalone kernel and the fused blur+solve+update kernel, in three
 // steps so that the R1 neighbourhood can be fetched in more than one way:
 //   ffl_um_locate   where pixel (x, y) displaced by (dx, dy) lands in R1 and its bilinear weights

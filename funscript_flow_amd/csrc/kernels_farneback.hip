@@ -72,6 +72,18 @@ __device__ __forceinline__ void ffl_resize_coord(int d, int src, double scale, i
     f = fx;
 }
 
+// the same for scale == 0.5 exactly (a x2 upsample of an even-sized level): (d + 0.5) * 0.5 - 0.5 = d/2 - 0.25 is exact in
+// double and in float, so floor and fraction follow from the parity of d -- identical results without the f64 arithmetic
+__device__ __forceinline__ void ffl_resize_coord_half(int d, int src, int &i0, int &i1, float &f) {
+    int sx = (d - 1) >> 1;
+    float fx = (d & 1) ? 0.25f : 0.75f;
+    if (d == 0) { sx = 0; fx = 0.f; }
+    if (sx >= src - 1) { sx = src - 1; fx = 0.f; }
+    i0 = sx;
+    i1 = sx + 1 < src ? sx + 1 : src - 1;
+    f = fx;
+}
+
 // Two plain streaming kernels per level, no LDS and no barriers (the earlier LDS-tiled version spent
 // its time in four dependent phases per workgroup and never filled the device at the coarse levels):
 //   k_pyr_h  one lane per (row y, output column d, lerp side q): horizontal blur of the full-resolution
@@ -1298,8 +1310,10 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
     // deeper (the next item's R1 gathers in flight as well) spilled too, 1900 us.
     struct UStageA {
         float a1, b1;
-        float2 p[4];
+        float4 c0, c1;      // rows ya0 / ya1 of the coarse flow, columns xq and xq + 1 (one 16-byte load each)
+        bool first0, first1;  // column xa0 / xa1 is the first of the two
     };
+    const bool half_scale = usx == 0.5 && usy == 0.5;
     auto phase_u = [&](int y0, int jbase, int nrows) {
         const int N = LW * nrows;
         auto coords = [&](int i, int &r, int &tx, int &gx, int &gy) {
@@ -1314,13 +1328,24 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
             coords(i, r, tx, gx, gy);
             if (FIRST == 1) {
                 int xa0, xa1, ya0, ya1;
-                ffl_resize_coord(gx, pw, usx, xa0, xa1, A.a1);
-                ffl_resize_coord(gy, ph, usy, ya0, ya1, A.b1);
+                if (half_scale) {  // uniform: the usual case (even level sizes) without the f64 coordinate arithmetic
+                    ffl_resize_coord_half(gx, pw, xa0, xa1, A.a1);
+                    ffl_resize_coord_half(gy, ph, ya0, ya1, A.b1);
+                } else {
+                    ffl_resize_coord(gx, pw, usx, xa0, xa1, A.a1);
+                    ffl_resize_coord(gy, ph, usy, ya0, ya1, A.b1);
+                }
                 const float *pf = reinterpret_cast<const float *>(prevf);
                 const unsigned r0o = (unsigned)ya0 * (unsigned)pw, r1o = (unsigned)ya1 * (unsigned)pw;
                 // global-address loads (ffl_gload2): behind a FLAT load the compiler can only wait for "everything"
-                A.p[0] = ffl_gload2(pf, 8u * (r0o + xa0)); A.p[1] = ffl_gload2(pf, 8u * (r0o + xa1));
-                A.p[2] = ffl_gload2(pf, 8u * (r1o + xa0)); A.p[3] = ffl_gload2(pf, 8u * (r1o + xa1));
+                // the two x-neighbours of a row with ONE 16-byte load (a wave64 dwordx4 costs the vector-memory path less
+                // than a dwordx2): columns xq, xq + 1 with xq = min(xa0, pw - 2) always lie inside the row, and xa0, xa1
+                // are each one of them (xa1 = xa0 + 1, or = xa0 at the right border); the choice is made at the use
+                const int xq = min(xa0, pw - 2);
+                A.c0 = ffl_gload4(pf, 8u * (r0o + xq));
+                A.c1 = ffl_gload4(pf, 8u * (r1o + xq));
+                A.first0 = xa0 == xq;
+                A.first1 = xa1 == xq;
             }
             return A;
         };
@@ -1336,10 +1361,14 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
             float2 f = make_float2(0.f, 0.f);
             if (FIRST == 1) {
                 const float a0 = 1.f - A.a1, b0 = 1.f - A.b1;
-                float t0 = A.p[0].x * a0 + A.p[1].x * A.a1, t1 = A.p[2].x * a0 + A.p[3].x * A.a1;
+                const float2 p00 = A.first0 ? make_float2(A.c0.x, A.c0.y) : make_float2(A.c0.z, A.c0.w);
+                const float2 p01 = A.first1 ? make_float2(A.c0.x, A.c0.y) : make_float2(A.c0.z, A.c0.w);
+                const float2 p10 = A.first0 ? make_float2(A.c1.x, A.c1.y) : make_float2(A.c1.z, A.c1.w);
+                const float2 p11 = A.first1 ? make_float2(A.c1.x, A.c1.y) : make_float2(A.c1.z, A.c1.w);
+                float t0 = p00.x * a0 + p01.x * A.a1, t1 = p10.x * a0 + p11.x * A.a1;
                 f.x = (t0 * b0 + t1 * A.b1) * 2.0f;
-                t0 = A.p[0].y * a0 + A.p[1].y * A.a1;
-                t1 = A.p[2].y * a0 + A.p[3].y * A.a1;
+                t0 = p00.y * a0 + p01.y * A.a1;
+                t1 = p10.y * a0 + p11.y * A.a1;
                 f.y = (t0 * b0 + t1 * A.b1) * 2.0f;
             }
             float r0[5];
@@ -1354,8 +1383,8 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
             ffl_f2u t[5], u[5];
 #pragma unroll
             for (int c = 0; c < 5; c++) {
-                t[c] = *ffl_at<ffl_f2u>(R1 + c * plane, o1);
-                u[c] = *ffl_at<ffl_f2u>(R1 + c * plane, o1 + (unsigned)w);
+                t[c] = ffl_ld_corner(R1 + c * plane, o1);
+                u[c] = ffl_ld_corner(R1 + c * plane, o1 + (unsigned)w);
             }
             // unconditional (a lane without a next item re-requests its own corners, cache hits): a fixed number of
             // loads behind the gathers lets the wait below be "all but the last 4", not "all"
@@ -1528,8 +1557,8 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
                 const unsigned o1 = L.inside ? (unsigned)L.y1 * (unsigned)w + (unsigned)L.x1 : 0u;
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
-                    S.t[c] = *ffl_at<ffl_f2u>(R1 + c * plane, o1);
-                    S.u[c] = *ffl_at<ffl_f2u>(R1 + c * plane, o1 + (unsigned)w);
+                    S.t[c] = ffl_ld_corner(R1 + c * plane, o1);
+                    S.u[c] = ffl_ld_corner(R1 + c * plane, o1 + (unsigned)w);
                 }
                 return S;
             };
