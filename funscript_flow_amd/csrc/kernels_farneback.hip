@@ -1304,14 +1304,17 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
     // Software-pipelined phase U, one pixel per lane.  An item costs two DEPENDENT memory round trips (the coarse
     // flow's corners, then R1 at the displaced position); with 3 waves per SIMD the waves sat in s_waitcnt half of
     // their cycles.  The NEXT item's flow corners are requested right after the current item's gathers, so that
-    // round trip runs under the gathers' wait and the item's arithmetic (level-0 launch 1850 -> 1790 us).  One pixel
-    // per lane (not the pair of the standalone kernel) keeps the two items in flight within the 168-register budget
-    // of 3 waves per SIMD: the pair version of the same pipeline spilled 55 registers and ran at 2720 us; one stage
-    // deeper (the next item's R1 gathers in flight as well) spilled too, 1900 us.
+    // round trip runs under the gathers' wait and the item's arithmetic.  One pixel per lane (not the pair of the
+    // standalone kernel) keeps the two items in flight within the 168-register budget of 3 waves per SIMD: the pair
+    // version of the same pipeline spilled 55 registers; one stage deeper (the next item's R1 gathers in flight as
+    // well) spilled too.  Load widths follow the cost of a wave64 global load on the CU's vector-memory path
+    // (profiles/tools/micro/vmem_issue.hip: 4 / 8 / 16 bytes per lane = 6.3 / 19.5 / 16.7 cycles): dwords for R0 and
+    // the R1 corners, one 16-byte load per coarse-flow row, never 8 bytes.  DESIGN.md section 4, round 2 (v), (vi).
     struct UStageA {
         float a1, b1;
         float4 c0, c1;      // rows ya0 / ya1 of the coarse flow, columns xq and xq + 1 (one 16-byte load each)
         bool first0, first1;  // column xa0 / xa1 is the first of the two
+        int r, tx, gx, gy;    // the item's coordinates, formed once
     };
     const bool half_scale = usx == 0.5 && usy == 0.5;
     auto phase_u = [&](int y0, int jbase, int nrows) {
@@ -1324,8 +1327,8 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
         };
         auto issue = [&](int i) {
             UStageA A;
-            int r, tx, gx, gy;
-            coords(i, r, tx, gx, gy);
+            coords(i, A.r, A.tx, A.gx, A.gy);
+            const int gx = A.gx, gy = A.gy;
             if (FIRST == 1) {
                 int xa0, xa1, ya0, ya1;
                 if (half_scale) {  // uniform: the usual case (even level sizes) without the f64 coordinate arithmetic
@@ -1337,8 +1340,8 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
                 }
                 const float *pf = reinterpret_cast<const float *>(prevf);
                 const unsigned r0o = (unsigned)ya0 * (unsigned)pw, r1o = (unsigned)ya1 * (unsigned)pw;
-                // global-address loads (ffl_gload2): behind a FLAT load the compiler can only wait for "everything"
-                // the two x-neighbours of a row with ONE 16-byte load (a wave64 dwordx4 costs the vector-memory path less
+                // global-address loads (ffl_gload4): behind a FLAT load the compiler can only wait for "everything".
+                // The two x-neighbours of a row with ONE 16-byte load (a wave64 dwordx4 costs the vector-memory path less
                 // than a dwordx2): columns xq, xq + 1 with xq = min(xa0, pw - 2) always lie inside the row, and xa0, xa1
                 // are each one of them (xa1 = xa0 + 1, or = xa0 at the right border); the choice is made at the use
                 const int xq = min(xa0, pw - 2);
@@ -1354,8 +1357,7 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
         UStageA A = issue(i);
 #pragma unroll 1
         for (;;) {
-            int r, tx, gx, gy;
-            coords(i, r, tx, gx, gy);
+            const int r = A.r, tx = A.tx, gx = A.gx, gy = A.gy;
             const int inext = i + 256;
             const bool more = inext < N;
             float2 f = make_float2(0.f, 0.f);
@@ -1387,7 +1389,7 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
                 u[c] = ffl_ld_corner(R1 + c * plane, o1 + (unsigned)w);
             }
             // unconditional (a lane without a next item re-requests its own corners, cache hits): a fixed number of
-            // loads behind the gathers lets the wait below be "all but the last 4", not "all"
+            // loads behind the gathers lets the wait below be "all but the last 2", not "all"
             const UStageA Anext = issue(more ? inext : i);
             float b[5];
 #pragma unroll
@@ -1533,7 +1535,7 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
             // One pixel per lane, lanes along x (a wave = one 64-pixel tile row, wave q takes rows q, q+4, q+8, q+12),
             // double-buffered: the R0 values and R1 corners of the lane's next row are requested before the current
             // row's arithmetic, so only the first of the four round trips is exposed.  No divergent branch touches a
-            // loaded value (ffl_um_finish<false>), so the waits are "all but the newest 15", never "all".
+            // loaded value (ffl_um_finish<false>), so the waits are "all but the next row's 25", never "all".
             struct UmRow {
                 float2 f;
                 float a00, a01, a10, a11;
