@@ -206,10 +206,11 @@ __device__ __forceinline__ float4 ffl_gload4(const void *base, size_t byte_off) 
 }
 
 // 8- and 16-byte vectors that are only 4-byte aligned: gfx950 global loads/stores of dwordx2/x4 need
-// dword alignment only.  Wider accesses pay where they cut the number of lane requests to the vector L1
-// (byte taps of the pyramid fetched as words: 54 -> 22 us; one 16-byte R1 load serving two pixels instead
-// of two 8-byte gathers: K5 -7 %); merely halving the instruction count at the same bytes did not
-// (phase V of k_blur_solve with 8-byte loads was slower than with 4-byte loads).
+// dword alignment only.  What a wave64 global load costs the CU's vector-memory path (cache-resident data, lanes
+// contiguous; profiles/tools/micro/vmem_issue.hip): 4 bytes per lane 6.3 cycles, 16 bytes 16.7, 8 bytes 19.5 -- so
+// streams use 16-byte accesses (byte taps of the pyramid fetched as words: 54 -> 22 us; PolyExp tiles, flow rows),
+// gathers use dwords, and 8-byte loads are avoided (phase V of k_blur_solve with 8-byte loads was slower than with
+// dwords; the R1 corner pairs as two dwords instead of one dwordx2: folded launch -3.4 %).
 struct __attribute__((packed, aligned(4))) ffl_f2u { float x, y; };
 struct __attribute__((packed, aligned(4))) ffl_f4u { float x, y, z, w; };
 
@@ -260,47 +261,17 @@ __device__ __forceinline__ UmLoc ffl_um_locate(int w, int h, int x, int y, float
     return L;
 }
 
-// the two horizontally adjacent corners of a row with one 8-byte load each
-__device__ __forceinline__ void ffl_um_gather(const UmLoc &L, const float *__restrict__ R1, size_t plane, int w,
-                                              float (&b)[5]) {
-    const unsigned o = (unsigned)L.y1 * (unsigned)w + (unsigned)L.x1;
-#pragma unroll
-    for (int c = 0; c < 5; c++) {
-        const ffl_f2u t = *ffl_at<ffl_f2u>(R1 + c * plane, o);                 // (x1, y1), (x1+1, y1)
-        const ffl_f2u u = *ffl_at<ffl_f2u>(R1 + c * plane, o + (unsigned)w);   // (x1, y1+1), (x1+1, y1+1)
-        b[c] = L.a00 * t.x + L.a01 * t.y + L.a10 * u.x + L.a11 * u.y;
-    }
-}
-
-// BRANCHY: the inside / outside cases as a divergent branch (the standalone kernel and the fused update of k_blur_solve:
-// the select form made k_blur_solve<true,0> 4 % slower) or as selects (the pipelined phase U: a divergent branch around
-// loaded values makes the compiler wait for every outstanding load, the prefetched ones included).
-template <bool BRANCHY = true>
+// The inside / outside cases are selects, not a branch: a divergent branch around loaded values makes the compiler wait
+// for every outstanding load (vmcnt(0)), the next item's prefetched ones included.
 __device__ __forceinline__ void ffl_um_finish(const float (&r0)[5], const float (&b)[5], bool inside, int w, int h, int x,
                                               int y, float dx, float dy, float (&out)[5]) {
     // border[5] = {0.14, 0.14, 0.4472, 0.4472, 0.4472} as selects (no runtime-indexed array)
 #define FFL_BORDER(i) ((i) < 2 ? 0.14f : 0.4472f)
-    float r2, r3, r4, r5, r6;
-    if (BRANCHY) {
-        if (inside) {
-            r2 = b[0];
-            r3 = b[1];
-            r4 = (r0[2] + b[2]) * 0.5f;
-            r5 = (r0[3] + b[3]) * 0.5f;
-            r6 = (r0[4] + b[4]) * 0.25f;
-        } else {
-            r2 = r3 = 0.f;
-            r4 = r0[2];
-            r5 = r0[3];
-            r6 = r0[4] * 0.5f;
-        }
-    } else {
-        r2 = inside ? b[0] : 0.f;
-        r3 = inside ? b[1] : 0.f;
-        r4 = inside ? (r0[2] + b[2]) * 0.5f : r0[2];
-        r5 = inside ? (r0[3] + b[3]) * 0.5f : r0[3];
-        r6 = inside ? (r0[4] + b[4]) * 0.25f : r0[4] * 0.5f;
-    }
+    float r2 = inside ? b[0] : 0.f;
+    float r3 = inside ? b[1] : 0.f;
+    float r4 = inside ? (r0[2] + b[2]) * 0.5f : r0[2];
+    float r5 = inside ? (r0[3] + b[3]) * 0.5f : r0[3];
+    float r6 = inside ? (r0[4] + b[4]) * 0.25f : r0[4] * 0.5f;
     r2 = (r0[0] - r2) * 0.5f;
     r3 = (r0[1] - r3) * 0.5f;
     r2 += r4 * dy + r6 * dx;
@@ -316,72 +287,4 @@ __device__ __forceinline__ void ffl_um_finish(const float (&r0)[5], const float 
     out[2] = r5 * r5 + r6 * r6;
     out[3] = r4 * r2 + r6 * r3;
     out[4] = r6 * r2 + r5 * r3;
-}
-
-// Two horizontally adjacent pixels (x, y), (x+1, y) per lane: R0 read and M written with 8-byte
-// accesses.  `second` is false when x+1 is outside the image; `store` predicates the M writes.
-// R1 fetch: neighbouring pixels move almost alike, so the two pixels' corner pairs usually sit in the same
-// two rows within 4 consecutive columns -- then ONE 16-byte load per row and channel serves both pixels
-// (10 loads instead of 20).  The choice is made per wave (all lanes or none), so there is no divergence.
-// the arithmetic of ffl_um_pair without the stores: ma / mb = the 5 products of pixel (x, y) / (x+1, y)
-// (mb = those of (x, y) again when `second` is false)
-__device__ __forceinline__ void ffl_um_pair_values(const float *__restrict__ R0, const float *__restrict__ R1,
-                                                   size_t plane, int w, int h, int x, int y, float2 f0, float2 f1,
-                                                   bool second, float (&ma)[5], float (&mb)[5]) {
-    const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
-    float ra[5], rb[5];
-    if (second) {
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            const ffl_f2u t = *ffl_at<ffl_f2u>(R0 + c * plane, o);
-            ra[c] = t.x;
-            rb[c] = t.y;
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 5; c++) ra[c] = rb[c] = *ffl_at<float>(R0 + c * plane, o);
-    }
-    const int xb = second ? x + 1 : x;
-    const UmLoc La = ffl_um_locate(w, h, x, y, f0.x, f0.y), Lb = ffl_um_locate(w, h, xb, y, f1.x, f1.y);
-    float ba[5] = {0.f, 0.f, 0.f, 0.f, 0.f}, bb[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-    const int dxx = Lb.x1 - La.x1;
-    const bool span = La.inside && Lb.inside && La.y1 == Lb.y1 && (unsigned)dxx <= 2u && La.x1 + 3 < w;
-    if (__all(span)) {
-        const unsigned o1 = (unsigned)La.y1 * (unsigned)w + (unsigned)La.x1;
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            const ffl_f4u t = *ffl_at<ffl_f4u>(R1 + c * plane, o1);                // row y1,   columns x1 .. x1+3
-            const ffl_f4u u = *ffl_at<ffl_f4u>(R1 + c * plane, o1 + (unsigned)w);  // row y1+1
-            ba[c] = La.a00 * t.x + La.a01 * t.y + La.a10 * u.x + La.a11 * u.y;
-            const float t0 = dxx == 0 ? t.x : (dxx == 1 ? t.y : t.z), t1 = dxx == 0 ? t.y : (dxx == 1 ? t.z : t.w);
-            const float u0 = dxx == 0 ? u.x : (dxx == 1 ? u.y : u.z), u1 = dxx == 0 ? u.y : (dxx == 1 ? u.z : u.w);
-            bb[c] = Lb.a00 * t0 + Lb.a01 * t1 + Lb.a10 * u0 + Lb.a11 * u1;
-        }
-    } else {
-        if (La.inside) ffl_um_gather(La, R1, plane, w, ba);
-        if (Lb.inside) ffl_um_gather(Lb, R1, plane, w, bb);
-    }
-    ffl_um_finish(ra, ba, La.inside, w, h, x, y, f0.x, f0.y, ma);
-    ffl_um_finish(rb, bb, Lb.inside, w, h, xb, y, f1.x, f1.y, mb);
-}
-
-__device__ __forceinline__ void ffl_um_pair(const float *__restrict__ R0, const float *__restrict__ R1, size_t plane,
-                                            int w, int h, int x, int y, float2 f0, float2 f1, bool second, bool store,
-                                            float *__restrict__ Mo) {
-    float ma[5], mb[5];
-    ffl_um_pair_values(R0, R1, plane, w, h, x, y, f0, f1, second, ma, mb);
-    if (!store) return;
-    const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
-    if (second) {
-#pragma unroll
-        for (int c = 0; c < 5; c++) {
-            ffl_f2u t;
-            t.x = ma[c];
-            t.y = mb[c];
-            *ffl_at<ffl_f2u>(Mo + c * plane, o) = t;
-        }
-    } else {
-#pragma unroll
-        for (int c = 0; c < 5; c++) *ffl_at<float>(Mo + c * plane, o) = ma[c];
-    }
 }

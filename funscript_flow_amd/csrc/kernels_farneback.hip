@@ -1035,82 +1035,113 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
                                                          float *__restrict__ M, size_t M_stride, int w,
                                                          int h, int pw, int ph, double usx, double usy, int store_flow,
                                                          int nB, int order) {
+    // One pixel per lane, lanes along x (a wave = one 64-pixel tile row; wave q takes rows q, q+4, q+8, q+12), as the
+    // fused update of k_blur_solve: all four rows' flow vectors first, then R0 + the R1 corners of the lane's NEXT row
+    // are requested before the current row's arithmetic.  Dword loads for R0 / R1, 16-byte loads for the coarse flow
+    // (a wave64 8-byte load costs the vector-memory path three dword loads: profiles/tools/micro/vmem_issue.hip).
     int b, tile_x, tile_y;
     if (!ffl_tile_coord((w + 63) / 64, (h + 15) / 16, nB, order, b, tile_x, tile_y)) return;
-    // two adjacent pixels per lane (8-byte R0 / M / 16-byte flow accesses): 32 lanes span the 64-wide
-    // tile, a wave covers 2 rows, the workgroup 8 rows per pass, 2 passes
-    const int x = tile_x * 64 + 2 * (threadIdx.x & 31);
-    if (x >= w) return;
-    const bool second = x + 1 < w;
+    const int lx = threadIdx.x & 63, x0 = tile_x * 64, x = min(x0 + lx, w - 1);
+    const bool xin = x0 + lx < w;
     const float *R0 = R + (size_t)pt->u0[b] * R_stride, *R1 = R + (size_t)pt->u1[b] * R_stride;
-    float2 *flow = reinterpret_cast<float2 *>(pt->flow[level][b]);
-    const float2 *prev = reinterpret_cast<const float2 *>(pt->flow[min(level + 1, FFL_MAX_LEVELS - 1)][b]);
-    int xa0 = 0, xa1 = 0, xb0 = 0, xb1 = 0;
-    float aa1 = 0.f, ab1 = 0.f;
-    constexpr bool UPSAMPLE = MODE == 1;
-    if (UPSAMPLE) {
-        ffl_resize_coord(x, pw, usx, xa0, xa1, aa1);
-        ffl_resize_coord(second ? x + 1 : x, pw, usx, xb0, xb1, ab1);
-    }
+    float *flow = pt->flow[level][b];
+    const float *pf = pt->flow[min(level + 1, FFL_MAX_LEVELS - 1)][b];
     float *Mb = M + (size_t)b * M_stride;
-    // branch-free over the lane's 2 rows (clamped loads, predicated stores): all loads in flight together
+    constexpr int NR = 4;
+    int yr[NR];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const int yy = tile_y * 16 + (threadIdx.x >> 5) + 8 * k;
-        const bool in = yy < h;
-        const int y = min(yy, h - 1);
-        const size_t o = (size_t)y * w + x;
-        float2 f0, f1;
-        if (UPSAMPLE) {
-            int y0, y1;
-            float b1;
-            ffl_resize_coord(y, ph, usy, y0, y1, b1);
-            const float b0 = 1.f - b1;
-            const float *pf = reinterpret_cast<const float *>(prev);  // wave-uniform base + 32-bit offsets (ffl_at)
-            const unsigned r0o = (unsigned)y0 * (unsigned)pw, r1o = (unsigned)y1 * (unsigned)pw;
-            {
-                const float a1 = aa1, a0 = 1.f - a1;
-                const float2 p00 = *ffl_at<float2>(pf, 2u * (r0o + xa0)), p01 = *ffl_at<float2>(pf, 2u * (r0o + xa1)),
-                             p10 = *ffl_at<float2>(pf, 2u * (r1o + xa0)), p11 = *ffl_at<float2>(pf, 2u * (r1o + xa1));
-                float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
-                f0.x = (t0 * b0 + t1 * b1) * 2.0f;
-                t0 = p00.y * a0 + p01.y * a1;
-                t1 = p10.y * a0 + p11.y * a1;
-                f0.y = (t0 * b0 + t1 * b1) * 2.0f;
-            }
-            {
-                const float a1 = ab1, a0 = 1.f - a1;
-                const float2 p00 = *ffl_at<float2>(pf, 2u * (r0o + xb0)), p01 = *ffl_at<float2>(pf, 2u * (r0o + xb1)),
-                             p10 = *ffl_at<float2>(pf, 2u * (r1o + xb0)), p11 = *ffl_at<float2>(pf, 2u * (r1o + xb1));
-                float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
-                f1.x = (t0 * b0 + t1 * b1) * 2.0f;
-                t0 = p00.y * a0 + p01.y * a1;
-                t1 = p10.y * a0 + p11.y * a1;
-                f1.y = (t0 * b0 + t1 * b1) * 2.0f;
-            }
-            // the upsampled field is consumed right here; nothing downstream reads it (k_blur_solve overwrites the
-            // flow without reading it), so it only goes to memory for the debug capture
-            if (in && store_flow) {
-                if (second) {
-                    ffl_f4u t;
-                    t.x = f0.x; t.y = f0.y; t.z = f1.x; t.w = f1.y;
-                    *reinterpret_cast<ffl_f4u *>(flow + o) = t;
-                } else {
-                    flow[o] = f0;
-                }
-            }
-        } else if (MODE == 2) {
-            f0 = f1 = make_float2(0.f, 0.f);
-        } else {
-            if (second) {
-                const ffl_f4u t = *reinterpret_cast<const ffl_f4u *>(flow + o);
-                f0 = make_float2(t.x, t.y);
-                f1 = make_float2(t.z, t.w);
-            } else {
-                f0 = f1 = flow[o];
-            }
+    for (int k = 0; k < NR; k++) yr[k] = tile_y * 16 + (threadIdx.x >> 6) + 4 * k;
+    float2 f[NR];
+    if (MODE == 1) {
+        const bool half_scale = usx == 0.5 && usy == 0.5;
+        int xa0, xa1;
+        float a1;
+        if (half_scale) ffl_resize_coord_half(x, pw, xa0, xa1, a1);
+        else ffl_resize_coord(x, pw, usx, xa0, xa1, a1);
+        const int xq = min(xa0, pw - 2);   // columns xq, xq + 1 lie inside the row; xa0 and xa1 are each one of them
+        const bool first0 = xa0 == xq, first1 = xa1 == xq;
+        const float a0 = 1.f - a1;
+        float4 c0[NR], c1[NR];
+        float b1[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            int ya0, ya1;
+            const int y = min(yr[k], h - 1);
+            if (half_scale) ffl_resize_coord_half(y, ph, ya0, ya1, b1[k]);
+            else ffl_resize_coord(y, ph, usy, ya0, ya1, b1[k]);
+            c0[k] = ffl_gload4(pf, 8u * ((unsigned)ya0 * (unsigned)pw + xq));
+            c1[k] = ffl_gload4(pf, 8u * ((unsigned)ya1 * (unsigned)pw + xq));
         }
-        ffl_um_pair(R0, R1, plane, w, h, x, y, f0, f1, second, in, Mb);
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const float b0 = 1.f - b1[k];
+            const float2 p00 = first0 ? make_float2(c0[k].x, c0[k].y) : make_float2(c0[k].z, c0[k].w);
+            const float2 p01 = first1 ? make_float2(c0[k].x, c0[k].y) : make_float2(c0[k].z, c0[k].w);
+            const float2 p10 = first0 ? make_float2(c1[k].x, c1[k].y) : make_float2(c1[k].z, c1[k].w);
+            const float2 p11 = first1 ? make_float2(c1[k].x, c1[k].y) : make_float2(c1[k].z, c1[k].w);
+            float t0 = p00.x * a0 + p01.x * a1, t1 = p10.x * a0 + p11.x * a1;
+            f[k].x = (t0 * b0 + t1 * b1[k]) * 2.0f;
+            t0 = p00.y * a0 + p01.y * a1;
+            t1 = p10.y * a0 + p11.y * a1;
+            f[k].y = (t0 * b0 + t1 * b1[k]) * 2.0f;
+        }
+    } else if (MODE == 0) {
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            const unsigned o = (unsigned)min(yr[k], h - 1) * (unsigned)w + (unsigned)x;
+            const FFL_GLOBAL float *q = (const FFL_GLOBAL float *)flow + 2u * o;
+            f[k] = make_float2(q[0], q[1]);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NR; k++) f[k] = make_float2(0.f, 0.f);
+    }
+    struct UmRow {
+        float a00, a01, a10, a11;
+        bool inside;
+        float r0[5];
+        ffl_f2u t[5], u[5];
+    };
+    auto issue = [&](int k) {
+        UmRow S;
+        const int y = min(yr[k], h - 1);
+        const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
+#pragma unroll
+        for (int c = 0; c < 5; c++) S.r0[c] = *ffl_at<float>(R0 + c * plane, o);
+        const UmLoc L = ffl_um_locate(w, h, x, y, f[k].x, f[k].y);
+        S.a00 = L.a00; S.a01 = L.a01; S.a10 = L.a10; S.a11 = L.a11; S.inside = L.inside;
+        const unsigned o1 = L.inside ? (unsigned)L.y1 * (unsigned)w + (unsigned)L.x1 : 0u;
+#pragma unroll
+        for (int c = 0; c < 5; c++) {
+            S.t[c] = ffl_ld_corner(R1 + c * plane, o1);
+            S.u[c] = ffl_ld_corner(R1 + c * plane, o1 + (unsigned)w);
+        }
+        return S;
+    };
+    UmRow cur = issue(0);
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        UmRow nxt;
+        if (k + 1 < NR) nxt = issue(k + 1);
+        const bool in = xin && yr[k] < h;
+        const int y = min(yr[k], h - 1);
+        const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
+        // the upsampled field is consumed right here; nothing downstream reads it (k_blur_solve overwrites the flow
+        // without reading it), so it only goes to memory for the debug capture
+        if (MODE == 1 && in && store_flow) {
+            flow[2u * o] = f[k].x;
+            flow[2u * o + 1u] = f[k].y;
+        }
+        float bb[5];
+#pragma unroll
+        for (int c = 0; c < 5; c++) bb[c] = cur.a00 * cur.t[c].x + cur.a01 * cur.t[c].y + cur.a10 * cur.u[c].x + cur.a11 * cur.u[c].y;
+        float m[5];
+        ffl_um_finish(cur.r0, bb, cur.inside, w, h, x, y, f[k].x, f[k].y, m);
+        if (in) {
+#pragma unroll
+            for (int c = 0; c < 5; c++) *ffl_at<float>(Mb + c * plane, o) = m[c];
+        }
+        if (k + 1 < NR) cur = nxt;
     }
 }
 
@@ -1395,7 +1426,7 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
 #pragma unroll
             for (int c = 0; c < 5; c++) b[c] = L.a00 * t[c].x + L.a01 * t[c].y + L.a10 * u[c].x + L.a11 * u[c].y;
             float m[5];
-            ffl_um_finish<false>(r0, b, L.inside, w, h, gx, gy, f.x, f.y, m);
+            ffl_um_finish(r0, b, L.inside, w, h, gx, gy, f.x, f.y, m);
 #pragma unroll
             for (int c = 0; c < GC; c++) sM012[(c * TH + r) * UP + tx] = m[c];
 #pragma unroll
@@ -1535,7 +1566,7 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
             // One pixel per lane, lanes along x (a wave = one 64-pixel tile row, wave q takes rows q, q+4, q+8, q+12),
             // double-buffered: the R0 values and R1 corners of the lane's next row are requested before the current
             // row's arithmetic, so only the first of the four round trips is exposed.  No divergent branch touches a
-            // loaded value (ffl_um_finish<false>), so the waits are "all but the next row's 25", never "all".
+            // loaded value (ffl_um_finish uses selects), so the waits are "all but the next row's 25", never "all".
             struct UmRow {
                 float2 f;
                 float a00, a01, a10, a11;
@@ -1581,7 +1612,7 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
 #pragma unroll
                 for (int c = 0; c < 5; c++) bb[c] = cur.a00 * cur.t[c].x + cur.a01 * cur.t[c].y + cur.a10 * cur.u[c].x + cur.a11 * cur.u[c].y;
                 float m[5];
-                ffl_um_finish<false>(cur.r0, bb, cur.inside, w, h, x, y, cur.f.x, cur.f.y, m);
+                ffl_um_finish(cur.r0, bb, cur.inside, w, h, x, y, cur.f.x, cur.f.y, m);
                 if (in) {
 #pragma unroll
                     for (int c = 0; c < 5; c++) *ffl_at<float>(Mo + c * plane, o) = m[c];
