@@ -8,6 +8,9 @@
 
 #define P1_THREADS 256
 #define P1_RG 16          // rows a wave walks down (its row group)
+#ifndef P1_G
+#define P1_G 16            // rows of it whose loads are in flight together in k_pass1 (4: 118 us, 8: 111, 16: 105 at 1080p B = 32)
+#endif
 #define P1_STRIP 126      // useful pixels of a pass-1 strip: 64 lanes x 2 pixels minus one halo pixel per side
 #define P2_STRIP 128      // pass 2 needs no halo
 
@@ -80,33 +83,45 @@ __global__ __launch_bounds__(P1_THREADS) void k_pass1(const PairTab *__restrict_
         const int x = strip * P1_STRIP - 1 + 2 * lane, y0 = grp * P1_RG;  // the lane's pixels: x, x+1
         // a pixel counts if it is inside the image and not one of the strip's two halo pixels
         const bool ok0 = lane > 0 && x < w, ok1 = lane < 63 && x + 1 < w;
-        float2 up0, up1, c0, c1, dn0, dn1;
-        ffl_load_pair(flow, w, h, x, y0 - 1, up0, up1);
-        ffl_load_pair(flow, w, h, x, y0, c0, c1);
+        // Two groups of 8 rows.  All 10 rows a group needs are requested before anything is computed: written as one
+        // loop (load row y + 1, use rows y - 1 .. y + 1) the compiler put a full wait behind every load -- the uniform
+        // `pov_mode` branch and the lane exchanges sit between them -- and a wave paid 18 dependent round trips.
+        const int xa = min(max(x, 0), w - 2);   // the lane's 16-byte window starts here (inside the row)
+        const bool first0 = min(max(x, 0), w - 1) == xa, first1 = min(max(x + 1, 0), w - 1) == xa;
+#pragma unroll 1
+        for (int g = 0; g < P1_RG; g += P1_G) {
+            float4 raw[P1_G + 2];
 #pragma unroll
-        for (int r = 0; r < P1_RG; r++) {
-            const int y = y0 + r;
-            ffl_load_pair(flow, w, h, x, y + 1, dn0, dn1);  // clamped: rows past the end repeat row h-1
-            const bool row_ok = y < h;
-            sum += (ok0 && row_ok) ? (double)sqrtf(c0.x * c0.x + c0.y * c0.y) : 0.0;
-            sum += (ok1 && row_ok) ? (double)sqrtf(c1.x * c1.x + c1.y * c1.y) : 0.0;
-            if (!pov_mode) {
-                // horizontal neighbours: the adjacent lanes' pixels (clamped loads make x = 0 / w-1 see themselves)
-                const float left0 = __shfl_up(c1.y, 1, 64), right1 = __shfl_down(c0.y, 1, 64);
-                const float d0 = fabsf(ffl_grad(up0.x, dn0.x, y, h) + ffl_grad(left0, c1.y, x, w));
-                const float d1 = fabsf(ffl_grad(up1.x, dn1.x, y, h) + ffl_grad(c0.y, right1, x + 1, w));
-                const unsigned i0 = (unsigned)y * (unsigned)w + (unsigned)x;
-                if (ok0 && row_ok) {
-                    const unsigned long long k = ((unsigned long long)__float_as_uint(d0) << 32) | (unsigned long long)(0xFFFFFFFFu - i0);
-                    key = k > key ? k : key;
-                }
-                if (ok1 && row_ok) {
-                    const unsigned long long k = ((unsigned long long)__float_as_uint(d1) << 32) | (unsigned long long)(0xFFFFFFFFu - (i0 + 1u));
-                    key = k > key ? k : key;
+            for (int r = 0; r < P1_G + 2; r++) {
+                const int yc = min(max(y0 + g - 1 + r, 0), h - 1);   // clamped: rows past the end repeat row h-1
+                raw[r] = ffl_gload4(flow, 8u * ((unsigned)yc * (unsigned)w + (unsigned)xa));  // < 2^32: ffl_create
+            }
+#pragma unroll
+            for (int r = 0; r < P1_G; r++) {
+                const int y = y0 + g + r;
+                const float4 tu = raw[r], tc = raw[r + 1], td = raw[r + 2];
+                const float2 up0 = first0 ? make_float2(tu.x, tu.y) : make_float2(tu.z, tu.w), up1 = first1 ? make_float2(tu.x, tu.y) : make_float2(tu.z, tu.w);
+                const float2 c0 = first0 ? make_float2(tc.x, tc.y) : make_float2(tc.z, tc.w), c1 = first1 ? make_float2(tc.x, tc.y) : make_float2(tc.z, tc.w);
+                const float2 dn0 = first0 ? make_float2(td.x, td.y) : make_float2(td.z, td.w), dn1 = first1 ? make_float2(td.x, td.y) : make_float2(td.z, td.w);
+                const bool row_ok = y < h;
+                sum += (ok0 && row_ok) ? (double)sqrtf(c0.x * c0.x + c0.y * c0.y) : 0.0;
+                sum += (ok1 && row_ok) ? (double)sqrtf(c1.x * c1.x + c1.y * c1.y) : 0.0;
+                if (!pov_mode) {
+                    // horizontal neighbours: the adjacent lanes' pixels (clamped loads make x = 0 / w-1 see themselves)
+                    const float left0 = __shfl_up(c1.y, 1, 64), right1 = __shfl_down(c0.y, 1, 64);
+                    const float d0 = fabsf(ffl_grad(up0.x, dn0.x, y, h) + ffl_grad(left0, c1.y, x, w));
+                    const float d1 = fabsf(ffl_grad(up1.x, dn1.x, y, h) + ffl_grad(c0.y, right1, x + 1, w));
+                    const unsigned i0 = (unsigned)y * (unsigned)w + (unsigned)x;
+                    if (ok0 && row_ok) {
+                        const unsigned long long k = ((unsigned long long)__float_as_uint(d0) << 32) | (unsigned long long)(0xFFFFFFFFu - i0);
+                        key = k > key ? k : key;
+                    }
+                    if (ok1 && row_ok) {
+                        const unsigned long long k = ((unsigned long long)__float_as_uint(d1) << 32) | (unsigned long long)(0xFFFFFFFFu - (i0 + 1u));
+                        key = k > key ? k : key;
+                    }
                 }
             }
-            up0 = c0; up1 = c1;
-            c0 = dn0; c1 = dn1;
         }
     }
     key = ffl_wave_max_u64(key);
