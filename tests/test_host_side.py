@@ -242,3 +242,44 @@ def test_create_rejects_bad_geometry_before_touching_a_device():
     hdr = open(os.path.join(ROOT, "include", "ffl.h")).read()
     assert re.search(r"#define FFL_MAX_BATCH\s+256\b", hdr)
     assert re.search(r"#define FFL_MAXB\s+256\b", open(os.path.join(ROOT, "funscript_flow_amd", "csrc", "ffl_kernels.h")).read())
+
+
+def test_kernel_resource_budgets(tmp_path):
+    """The occupancy the kernels are designed for, read from the code objects inside the built library (no GPU needed):
+    no kernel spills to scratch; the folded k_blur_solve launches fit 3 workgroups per CU (<= 168 VGPRs, <= 53 KB LDS),
+    the other two 4 (<= 128 VGPRs, <= 40 KB).  A change that silently costs a wave per SIMD shows up here first."""
+    import re
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(f"{llvm}/llvm-objdump") and os.path.exists(f"{llvm}/llvm-readelf")):
+        pytest.skip("llvm-objdump / llvm-readelf not in this image")
+    from funscript_flow_amd import _capi
+    if not os.path.exists(_capi.LIB_PATH):
+        pytest.skip("libffl_hip.so has not been built")
+    so = shutil.copy(_capi.LIB_PATH, tmp_path / "lib.so")
+    subprocess.run([f"{llvm}/llvm-objdump", "--offloading", str(so)], cwd=tmp_path, capture_output=True, check=True)
+    kernels = {}
+    for co in sorted(tmp_path.glob("*gfx950")):
+        notes = subprocess.run([f"{llvm}/llvm-readelf", "--notes", str(co)], capture_output=True, text=True, check=True).stdout
+        for blk in notes.split("- .agpr_count:")[1:]:
+            g = {k: re.search(rf"\.{k}:\s+(\S+)", blk) for k in ("name", "vgpr_count", "private_segment_fixed_size", "group_segment_fixed_size")}
+            if all(g.values()):
+                kernels[g["name"].group(1)] = tuple(int(g[k].group(1)) for k in ("vgpr_count", "private_segment_fixed_size", "group_segment_fixed_size"))
+    assert len(kernels) >= 25, sorted(kernels)
+    for name, (vgpr, scratch, lds) in kernels.items():
+        assert scratch == 0, (name, "spills", scratch)
+
+    def one(prefix):
+        hit = [v for k, v in kernels.items() if k.startswith(prefix)]
+        assert len(hit) == 1, (prefix, sorted(kernels))
+        return hit[0]
+
+    for first in (1, 2):      # folded first iteration: 3 workgroups of 256 per CU
+        vgpr, _, lds = one(f"_Z12k_blur_solveILb1ELi{first}E")
+        assert vgpr <= 168 and lds <= 160 * 1024 // 3, (first, vgpr, lds)
+    for upd in (0, 1):        # second / third launch of a level: 4 workgroups per CU
+        vgpr, _, lds = one(f"_Z12k_blur_solveILb{upd}ELi0E")
+        assert vgpr <= 128 and lds <= 160 * 1024 // 4, (upd, vgpr, lds)
+    vgpr, _, lds = one("_Z15k_polyexp_multi")
+    assert vgpr <= 80 and lds <= 160 * 1024 // 6, (vgpr, lds)   # 6 workgroups per CU (LDS alone would allow 7)
