@@ -60,8 +60,8 @@ __device__ __forceinline__ int ffl_reflect101(int p, int n) {
 
 // `scale` = (double)src / dst, formed once on the host (IEEE division: the same double the oracle forms)
 __device__ __forceinline__ void ffl_resize_coord(int d, int src, double scale, int &i0, int &i1, float &f) {
-    // (an integer fast path for the x2 upsample -- floor = (d - 1) >> 1, fraction 0.75 / 0.25 -- removes five f64-rate
-    // instructions per coordinate and made the folded k_blur_solve launch 2.5 % SLOWER: not kept)
+    // (the x2 upsample of an even-sized level takes ffl_resize_coord_half below; useless while the phase waited for its
+    // loads, -1.5 % once it did not)
     float fx = (float)((d + 0.5) * scale - 0.5);
     int sx = (int)floorf(fx);
     fx -= sx;
