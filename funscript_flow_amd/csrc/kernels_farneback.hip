@@ -15,6 +15,10 @@
 //   k_blur_solve    HBM        28  (M 20 -> flow 8) [+68 when the next UpdateMatrices is fused; on large
 //                              levels the first iteration also runs the level's flow init + UpdateMatrices_0];
 //                              the flow is only stored by a level's last iteration (nothing reads it earlier)
+// Every UpdateMatrices (standalone, fused update, phase U of the folded first iteration) works one pixel per lane
+// with the next row's / item's loads requested before the current one's arithmetic, and sizes its loads by what a
+// wave64 load costs the CU's vector-memory path (4 / 8 / 16 bytes per lane: 6.3 / 19.5 / 16.7 cycles): dwords for the
+// gathers, 16 bytes for streams, never 8.  DESIGN.md section 4, "Round 2".
 #include "ffl_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
