@@ -329,3 +329,40 @@ def test_bench_prints_exactly_one_json_line():
               "vs_baseline", "dtype", "data", "config", "roofline", "checked"):
         assert k in d, k
     assert d["steps"] == 2 and d["n_gpus"] == 1 and d["checked"] is True
+
+
+def test_non_default_options_change_no_bit():
+    """tile_order = 1 (tile-major workgroup order), pyr_coarse = 0 (H + V kernel pairs for the coarse pyramid levels) and
+    copy_threads = 1 / 8 (staging copy split) are speed options: records, scalars and the flow field must be identical."""
+    from funscript_flow_amd.synth import gray_to_bgr
+    w, h, B = 640, 360, 8
+    frames = sine_translate_frames(B + 1, w, h, seed=21, amp=(3.0, 2.0), period=7, zoom=0.02)
+    bgr = gray_to_bgr(frames)
+
+    def run(**opts):
+        try:
+            for k, v in opts.items():
+                _capi.set_option(k, v)
+            with _capi.Context(w, h, max_batch=B, frame_slots=2 * B + 2, flow_slots=pipeline.min_flow_slots(B)) as ctx:
+                ctx.upload_frames(0, list(bgr))           # staged BGR upload: exercises the copy pool
+                slots = list(range(B))
+                ctx.flow_pairs(list(range(B)), list(range(1, B + 1)), slots)
+                recs = ctx.pass1_results(slots, 7.0)
+                centers = pipeline.smooth_centers([(r[0], r[1]) for r in recs])
+                dots = ctx.radial(slots, centers, [r[4] for r in recs], False)
+                flow = ctx.download_flow(B // 2)
+            return recs, dots, flow
+        finally:
+            _capi.set_option("tile_order", 0)
+            _capi.set_option("pyr_coarse", 1)
+            _capi.set_option("copy_threads", 4)
+
+    ref = run()
+    for opts in ({"tile_order": 1}, {"pyr_coarse": 0}, {"copy_threads": 1}, {"copy_threads": 8}, {"tile_order": 1, "fuse_first": 1}):
+        try:
+            got = run(**opts)
+        finally:
+            _capi.set_option("fuse_first", 10000)
+        assert [tuple(r) for r in got[0]] == [tuple(r) for r in ref[0]], opts
+        assert got[1] == ref[1], opts
+        assert np.array_equal(got[2], ref[2]), opts
