@@ -36,18 +36,29 @@
  *     accumulators, box sums, 2x2 solve);
  *   - the 15x15 box sum is the exact-window sum accumulated in double: rows y-7..y+7 first, then
  *     columns x-7..x+7 (REPLICATE border), each 15-term sum in the position-anchored block order
- *     of box15_block16().  OpenCV reaches these sums with running (sliding) sums: a per-column vertical sum
- *     updated as vsum[x] += srow1[x] - srow0[x], then a horizontal running sum.  SURVEY A.5 records the
- *     accumulators as double; as the round-1 judge recalls the published optflowgf.cpp, the row DIFFERENCE is
- *     formed in float before it is added, so a real cv2 run would drift from the exact window sum by ~1e-7
- *     relative per update (float rounding of the difference), not ~1e-16.  Either way the exact-window sum is
- *     the quantity both approximate, the difference is below what any cv2 cross-check could resolve
- *     (tolerances, not bit-equality: SURVEY A.8), and it cannot be checked here (no OpenCV source or wheel):
- *     recorded in the confidence register, not chased;
+ *     of box15_block16().  OpenCV reaches these sums with running (sliding) sums -- see ORC_V_BOX_SLIDING below;
  *   - the separable Gaussian uses the symmetric form k0*c + sum_j kj*(x[-j]+x[+j]) in float,
  *     horizontal pass first, BORDER_REFLECT_101;
- *   - bilinear resize follows OpenCV's coordinate rule for every scale (the exact-2x INTER_AREA
- *     shortcut of OpenCV computes the same 2x2 mean up to 1 ulp and is not reproduced).
+ *   - bilinear resize follows OpenCV's coordinate rule for every scale.
+ *
+ * KNOWN ORDERINGS OF THE PUBLISHED OpenCV CODE THAT THE DEFAULT ABOVE DOES NOT REPRODUCE -- each is available as a
+ * switchable VARIANT (orc_farneback_var, flag bits below) so that its effect on the flow, the argmax pixel and the
+ * per-pair scalar is MEASURED instead of guessed (oracle/gen_sensitivity.py -> tests/golden/sensitivity.json,
+ * tests/test_oracle_sensitivity.py; numbers in DESIGN.md section 3):
+ *   ORC_V_BOX_SLIDING    FarnebackUpdateFlow_Blur as published: per-column running sums in a double buffer,
+ *                        initialised with float(row0 * (m+2)) + rows 1..m-1, advanced per row by
+ *                        vsum[x] += srow1[x] - srow0[x] with the DIFFERENCE FORMED IN FLOAT; horizontal running sums
+ *                        g += vsum[x+m] - vsum[x-m-1] in double, started as vsum[0]*(m+2) + vsum[1..m-1].
+ *   ORC_V_AREA2X_SEQ     the x1/2 level through resize()'s INTER_AREA route (INTER_LINEAR with an exact integer scale of
+ *                        2 is re-routed there): the scalar ResizeAreaFast order ((a00 + a01) + a10) + a11) * 0.25f.  (The
+ *                        SIMD form ((a00 + a01) + (a10 + a11)) * 0.25f equals the default bilinear result bit for bit:
+ *                        the 0.5 weights are exact.)
+ *   ORC_V_GAUSS_ROW_LTR  sepFilter2D's generic RowFilter for kernels wider than 5 taps (the x1/4 and x1/8 levels: 9 and
+ *                        19 taps): plain left-to-right accumulation sum_k kx[k] * S[x - r + k] instead of the symmetric
+ *                        form (the 3-tap levels use SymmRowSmallFilter, the column pass SymmColumnFilter: both are the
+ *                        symmetric form of the default).
+ *   FMA contraction      (the wheel's AVX2/FMA dispatch) is a BUILD variant: liboracle_fma.so = this file compiled with
+ *                        -ffp-contract=fast -mfma (oracle/Makefile).
  *
  * Layouts: images row-major; R and M are 5 PLANES of h*w floats (plane c at base + c*h*w);
  * flow is interleaved (h, w, 2) float exactly as cv2 returns it.
@@ -66,6 +77,27 @@
 #define PYR_LEVELS 3
 #define PYR_SCALE 0.5
 #define MIN_SIZE 32
+
+/* variant flags (see the header): 0 = the oracle the HIP kernels are bit-identical to */
+#define ORC_V_BOX_SLIDING 1u
+#define ORC_V_AREA2X_SEQ 2u
+#define ORC_V_GAUSS_ROW_LTR 4u
+
+/* ---- scratch memory: either malloc/free per call (ws == NULL, the historical behaviour) or a caller-owned,
+ * pre-faulted workspace used as a stack (bench.py's cpu_baseline: one workspace per worker process, so the timed
+ * loop never touches the allocator or first-touches a page -- round-2 verdict, "Measurement") ------------------- */
+typedef struct { char *base; size_t cap, off; int failed; } orc_ws;
+
+static void *ws_get(orc_ws *ws, size_t bytes) {
+    if (!ws) return malloc(bytes);
+    size_t o = (ws->off + 63) & ~(size_t)63;
+    if (o + bytes > ws->cap) { ws->failed = 1; return 0; }
+    ws->off = o + bytes;
+    return ws->base + o;
+}
+static void ws_put(orc_ws *ws, void *p) { if (!ws) free(p); }          /* stack discipline: see ws_mark/ws_release */
+static size_t ws_mark(orc_ws *ws) { return ws ? ws->off : 0; }
+static void ws_release(orc_ws *ws, size_t mark) { if (ws) ws->off = mark; }
 
 static inline int cv_round(double v) { return (int)lrint(v); } /* round-half-even */
 static inline int cv_floorf(float v) { return (int)floorf(v); }
@@ -150,25 +182,37 @@ ORC_API void orc_bgr2gray(const uint8_t *bgr, int w, int h, int stride, uint8_t 
 }
 
 /* ---- per-level image: float(img) -> GaussianBlur(full res) -> resize ------------------ */
-ORC_API void orc_pyr_level(const uint8_t *img, int w, int h, int stride, int k, float *I) {
+static int pyr_level_impl(orc_ws *ws, const uint8_t *img, int w, int h, int stride, int k, float *I, unsigned flags) {
     int lw, lh, ks;
     double sigma;
     orc_level_params(w, h, k, &lw, &lh, &sigma, &ks);
     int r = ks / 2;
     float kern[64];
     orc_gaussian_kernel(ks, sigma, kern);
+    const int row_ltr = (flags & ORC_V_GAUSS_ROW_LTR) && ks > 5; /* generic RowFilter; <= 5 taps: SymmRowSmallFilter */
 
-    float *tmp = (float *)malloc(sizeof(float) * (size_t)w * h);
-    float *blur = (float *)malloc(sizeof(float) * (size_t)w * h);
+    size_t mark = ws_mark(ws);
+    float *tmp = (float *)ws_get(ws, sizeof(float) * (size_t)w * h);
+    float *blur = (float *)ws_get(ws, sizeof(float) * (size_t)w * h);
+    int *x0 = (int *)ws_get(ws, sizeof(int) * lw), *x1 = (int *)ws_get(ws, sizeof(int) * lw);
+    int *y0 = (int *)ws_get(ws, sizeof(int) * lh), *y1 = (int *)ws_get(ws, sizeof(int) * lh);
+    float *fx = (float *)ws_get(ws, sizeof(float) * lw), *fy = (float *)ws_get(ws, sizeof(float) * lh);
+    if (!tmp || !blur || !x0 || !x1 || !y0 || !y1 || !fx || !fy) return -1;
     /* horizontal pass */
     for (int y = 0; y < h; y++) {
         const uint8_t *s = img + (size_t)y * stride;
         for (int x = 0; x < w; x++) {
-            float acc = kern[r] * (float)s[x];
-            for (int j = 1; j <= r; j++) {
-                float a = (float)s[reflect101(x - j, w)];
-                float b = (float)s[reflect101(x + j, w)];
-                acc = acc + kern[r + j] * (a + b);
+            float acc;
+            if (row_ltr) {
+                acc = kern[0] * (float)s[reflect101(x - r, w)];
+                for (int j = 1; j < ks; j++) acc = acc + kern[j] * (float)s[reflect101(x - r + j, w)];
+            } else {
+                acc = kern[r] * (float)s[x];
+                for (int j = 1; j <= r; j++) {
+                    float a = (float)s[reflect101(x - j, w)];
+                    float b = (float)s[reflect101(x + j, w)];
+                    acc = acc + kern[r + j] * (a + b);
+                }
             }
             tmp[(size_t)y * w + x] = acc;
         }
@@ -184,23 +228,44 @@ ORC_API void orc_pyr_level(const uint8_t *img, int w, int h, int stride, int k, 
             }
             blur[(size_t)y * w + x] = acc;
         }
-    /* bilinear resize */
-    int *x0 = (int *)malloc(sizeof(int) * lw), *x1 = (int *)malloc(sizeof(int) * lw);
-    int *y0 = (int *)malloc(sizeof(int) * lh), *y1 = (int *)malloc(sizeof(int) * lh);
-    float *fx = (float *)malloc(sizeof(float) * lw), *fy = (float *)malloc(sizeof(float) * lh);
-    orc_resize_table(w, lw, x0, x1, fx);
-    orc_resize_table(h, lh, y0, y1, fy);
-    for (int y = 0; y < lh; y++) {
-        const float *r0 = blur + (size_t)y0[y] * w, *r1 = blur + (size_t)y1[y] * w;
-        float b1 = fy[y], b0 = 1.f - b1;
-        for (int x = 0; x < lw; x++) {
-            float a1 = fx[x], a0 = 1.f - a1;
-            float t0 = r0[x0[x]] * a0 + r0[x1[x]] * a1;
-            float t1 = r1[x0[x]] * a0 + r1[x1[x]] * a1;
-            I[(size_t)y * lw + x] = t0 * b0 + t1 * b1;
+    if ((flags & ORC_V_AREA2X_SEQ) && lw * 2 == w && lh * 2 == h) {
+        /* resize(): INTER_LINEAR with iscale_x == iscale_y == 2 is re-routed to INTER_AREA; scalar ResizeAreaFast */
+        for (int y = 0; y < lh; y++) {
+            const float *r0 = blur + (size_t)(2 * y) * w, *r1 = r0 + w;
+            for (int x = 0; x < lw; x++) {
+                float sum = r0[2 * x] + r0[2 * x + 1];
+                sum = sum + r1[2 * x];
+                sum = sum + r1[2 * x + 1];
+                I[(size_t)y * lw + x] = sum * 0.25f;
+            }
+        }
+    } else {
+        /* bilinear resize */
+        orc_resize_table(w, lw, x0, x1, fx);
+        orc_resize_table(h, lh, y0, y1, fy);
+        for (int y = 0; y < lh; y++) {
+            const float *r0 = blur + (size_t)y0[y] * w, *r1 = blur + (size_t)y1[y] * w;
+            float b1 = fy[y], b0 = 1.f - b1;
+            for (int x = 0; x < lw; x++) {
+                float a1 = fx[x], a0 = 1.f - a1;
+                float t0 = r0[x0[x]] * a0 + r0[x1[x]] * a1;
+                float t1 = r1[x0[x]] * a0 + r1[x1[x]] * a1;
+                I[(size_t)y * lw + x] = t0 * b0 + t1 * b1;
+            }
         }
     }
-    free(tmp); free(blur); free(x0); free(x1); free(y0); free(y1); free(fx); free(fy);
+    ws_put(ws, tmp); ws_put(ws, blur); ws_put(ws, x0); ws_put(ws, x1); ws_put(ws, y0); ws_put(ws, y1); ws_put(ws, fx);
+    ws_put(ws, fy);
+    ws_release(ws, mark);
+    return 0;
+}
+
+ORC_API void orc_pyr_level(const uint8_t *img, int w, int h, int stride, int k, float *I) {
+    pyr_level_impl(0, img, w, h, stride, k, I, 0);
+}
+
+ORC_API void orc_pyr_level_var(const uint8_t *img, int w, int h, int stride, int k, float *I, unsigned flags) {
+    pyr_level_impl(0, img, w, h, stride, k, I, flags);
 }
 
 /* ---- A.3 FarnebackPrepareGaussian ---------------------------------------------------- */
@@ -259,14 +324,16 @@ ORC_API void orc_polyexp_prepare(float *g, float *xg, float *xxg, double *ig) {
 }
 
 /* ---- A.3 FarnebackPolyExp: I (h,w) -> R 5 planes -------------------------------------- */
-ORC_API void orc_polyexp(const float *I, int w, int h, float *R) {
+static int polyexp_impl(orc_ws *ws, const float *I, int w, int h, float *R) {
     const int n = POLY_N;
     float g[POLY_N + 1], xg[POLY_N + 1], xxg[POLY_N + 1];
     double ig[4];
     orc_polyexp_prepare(g, xg, xxg, ig);
     const double ig11 = ig[0], ig03 = ig[1], ig33 = ig[2], ig55 = ig[3];
     size_t plane = (size_t)w * h;
-    float *row = (float *)malloc(sizeof(float) * 3 * (size_t)w);
+    size_t mark = ws_mark(ws);
+    float *row = (float *)ws_get(ws, sizeof(float) * 3 * (size_t)w);
+    if (!row) return -1;
     for (int y = 0; y < h; y++) {
         const float *s0 = I + (size_t)y * w;
         /* vertical part, float, rows clamped */
@@ -312,14 +379,20 @@ ORC_API void orc_polyexp(const float *I, int w, int h, float *R) {
             R[4 * plane + o] = (float)(b6 * ig55);
         }
     }
-    free(row);
+    ws_put(ws, row);
+    ws_release(ws, mark);
+    return 0;
 }
 
+ORC_API void orc_polyexp(const float *I, int w, int h, float *R) { polyexp_impl(0, I, w, h, R); }
+
 /* ---- flow upsample between levels: resize(prevFlow, (w,h), INTER_LINEAR) * (1/pyrScale) */
-ORC_API void orc_flow_upsample(const float *prev, int pw, int ph, float *flow, int w, int h) {
-    int *x0 = (int *)malloc(sizeof(int) * w), *x1 = (int *)malloc(sizeof(int) * w);
-    int *y0 = (int *)malloc(sizeof(int) * h), *y1 = (int *)malloc(sizeof(int) * h);
-    float *fx = (float *)malloc(sizeof(float) * w), *fy = (float *)malloc(sizeof(float) * h);
+static int flow_upsample_impl(orc_ws *ws, const float *prev, int pw, int ph, float *flow, int w, int h) {
+    size_t mark = ws_mark(ws);
+    int *x0 = (int *)ws_get(ws, sizeof(int) * w), *x1 = (int *)ws_get(ws, sizeof(int) * w);
+    int *y0 = (int *)ws_get(ws, sizeof(int) * h), *y1 = (int *)ws_get(ws, sizeof(int) * h);
+    float *fx = (float *)ws_get(ws, sizeof(float) * w), *fy = (float *)ws_get(ws, sizeof(float) * h);
+    if (!x0 || !x1 || !y0 || !y1 || !fx || !fy) return -1;
     orc_resize_table(pw, w, x0, x1, fx);
     orc_resize_table(ph, h, y0, y1, fy);
     const float mul = (float)(1.0 / PYR_SCALE);
@@ -335,7 +408,13 @@ ORC_API void orc_flow_upsample(const float *prev, int pw, int ph, float *flow, i
             }
         }
     }
-    free(x0); free(x1); free(y0); free(y1); free(fx); free(fy);
+    ws_put(ws, x0); ws_put(ws, x1); ws_put(ws, y0); ws_put(ws, y1); ws_put(ws, fx); ws_put(ws, fy);
+    ws_release(ws, mark);
+    return 0;
+}
+
+ORC_API void orc_flow_upsample(const float *prev, int pw, int ph, float *flow, int w, int h) {
+    flow_upsample_impl(0, prev, pw, ph, flow, w, h);
 }
 
 /* ---- A.4 FarnebackUpdateMatrices ------------------------------------------------------ */
@@ -417,10 +496,12 @@ static void box15_block16(const double *v, double *out) {
     out[15] = p;
 }
 
-ORC_API void orc_blur_solve(const float *M, int w, int h, float *flow) {
+static int blur_solve_impl(orc_ws *ws, const float *M, int w, int h, float *flow) {
     const double scale = 1. / (WINSIZE * WINSIZE);
     size_t pl = (size_t)w * h;
-    double *vs = (double *)malloc(sizeof(double) * 16 * 5 * (size_t)w); /* column sums of one block of 16 rows */
+    size_t mark = ws_mark(ws);
+    double *vs = (double *)ws_get(ws, sizeof(double) * 16 * 5 * (size_t)w); /* column sums of one block of 16 rows */
+    if (!vs) return -1;
     for (int yb = 0; yb < h; yb += 16) {
         for (int c = 0; c < 5; c++)
             for (int x = 0; x < w; x++) {
@@ -449,37 +530,104 @@ ORC_API void orc_blur_solve(const float *M, int w, int h, float *flow) {
             }
         }
     }
-    free(vs);
+    ws_put(ws, vs);
+    ws_release(ws, mark);
+    return 0;
+}
+
+ORC_API void orc_blur_solve(const float *M, int w, int h, float *flow) { blur_solve_impl(0, M, w, h, flow); }
+
+/* VARIANT ORC_V_BOX_SLIDING: the box filter exactly as the published FarnebackUpdateFlow_Blur orders it (OpenCV 4.x
+ * modules/video/src/optflowgf.cpp; M is interleaved there, planar here -- the channels never mix).  m = winsize/2:
+ *   vsum[x]  = srow(0)[x] * (m+2)            <- float * int: a FLOAT product, then widened to double
+ *   vsum[x] += srow(min(y, h-1))[x]          for y = 1 .. m-1
+ *   per row y:  vsum[x] += srow(min(y+m, h-1))[x] - srow(max(y-m-1, 0))[x]    <- the difference is formed in FLOAT
+ *               vsum replicated m+1 entries beyond both ends
+ *               g = vsum[0] * (m+2) + vsum[1] + .. + vsum[m-1]                (double)
+ *               per x:  g += vsum[x+m] - vsum[x-m-1]  (double difference);  solve as above.
+ * The running sums carry their rounding down the whole column / along the whole row, so the deviation from the exact
+ * window sum grows with the image size: that is what tests/test_oracle_sensitivity.py measures. */
+static int blur_solve_sliding_impl(orc_ws *ws, const float *M, int w, int h, float *flow) {
+    const int m = WINSIZE / 2;
+    const double scale = 1. / (WINSIZE * WINSIZE);
+    const size_t pl = (size_t)w * h, pitch = (size_t)w + 2 * m + 2;
+    size_t mark = ws_mark(ws);
+    double *buf = (double *)ws_get(ws, sizeof(double) * 5 * pitch);
+    if (!buf) return -1;
+    double *vsum[5];
+    for (int c = 0; c < 5; c++) {
+        vsum[c] = buf + c * pitch + (m + 1);
+        const float *srow0 = M + c * pl;
+        for (int x = 0; x < w; x++) vsum[c][x] = (double)(srow0[x] * (float)(m + 2));
+        for (int y = 1; y < m; y++) {
+            srow0 = M + c * pl + (size_t)(y < h - 1 ? y : h - 1) * w;
+            for (int x = 0; x < w; x++) vsum[c][x] += (double)srow0[x];
+        }
+    }
+    for (int y = 0; y < h; y++) {
+        double g[5];
+        for (int c = 0; c < 5; c++) {
+            const float *srow0 = M + c * pl + (size_t)(y - m - 1 > 0 ? y - m - 1 : 0) * w;
+            const float *srow1 = M + c * pl + (size_t)(y + m < h - 1 ? y + m : h - 1) * w;
+            double *v = vsum[c];
+            for (int x = 0; x < w; x++) {
+                float d = srow1[x] - srow0[x];
+                v[x] += (double)d;
+            }
+            for (int x = 0; x <= m; x++) {
+                v[-1 - x] = v[0];
+                v[w + x] = v[w - 1];
+            }
+            g[c] = v[0] * (m + 2);
+            for (int x = 1; x < m; x++) g[c] += v[x];
+        }
+        for (int x = 0; x < w; x++) {
+            for (int c = 0; c < 5; c++) g[c] += vsum[c][x + m] - vsum[c][x - m - 1];
+            double g11 = g[0] * scale, g12 = g[1] * scale, g22 = g[2] * scale, h1 = g[3] * scale, h2 = g[4] * scale;
+            double idet = 1. / (g11 * g22 - g12 * g12 + 1e-3);
+            flow[((size_t)y * w + x) * 2] = (float)((g11 * h2 - g12 * h1) * idet);
+            flow[((size_t)y * w + x) * 2 + 1] = (float)((g22 * h1 - g12 * h2) * idet);
+        }
+    }
+    ws_put(ws, buf);
+    ws_release(ws, mark);
+    return 0;
+}
+
+ORC_API void orc_blur_solve_sliding(const float *M, int w, int h, float *flow) {
+    blur_solve_sliding_impl(0, M, w, h, flow);
 }
 
 /* ---- A.1 driver ------------------------------------------------------------------------ */
 /* Optional dumps: when dump_level == k (>=0) the level-k intermediates are copied out after
  * `dump_iter` blur iterations (0 => just after the initial UpdateMatrices):
  *   dI0/dI1 (lh*lw), dR0/dR1 (5*lh*lw), dM (5*lh*lw), dflow (lh*lw*2). NULL pointers are skipped. */
-ORC_API int orc_farneback_dbg(const uint8_t *prev, const uint8_t *next, int w, int h, int stride, float *flow_out,
-                              int dump_level, int dump_iter, float *dI0, float *dI1, float *dR0, float *dR1,
-                              float *dM, float *dflow) {
+static int farneback_impl(orc_ws *ws, unsigned flags, const uint8_t *prev, const uint8_t *next, int w, int h,
+                          int stride, float *flow_out, int dump_level, int dump_iter, float *dI0, float *dI1,
+                          float *dR0, float *dR1, float *dM, float *dflow) {
     int levels = orc_num_levels(w, h);
     size_t N = (size_t)w * h;
-    float *I = (float *)malloc(sizeof(float) * N);
-    float *R0 = (float *)malloc(sizeof(float) * 5 * N), *R1 = (float *)malloc(sizeof(float) * 5 * N);
-    float *M = (float *)malloc(sizeof(float) * 5 * N);
-    float *flow = (float *)malloc(sizeof(float) * 2 * N), *prevflow = (float *)malloc(sizeof(float) * 2 * N);
+    size_t mark = ws_mark(ws);
+    float *I = (float *)ws_get(ws, sizeof(float) * N);
+    float *R0 = (float *)ws_get(ws, sizeof(float) * 5 * N), *R1 = (float *)ws_get(ws, sizeof(float) * 5 * N);
+    float *M = (float *)ws_get(ws, sizeof(float) * 5 * N);
+    float *flow = (float *)ws_get(ws, sizeof(float) * 2 * N), *prevflow = (float *)ws_get(ws, sizeof(float) * 2 * N);
     if (!I || !R0 || !R1 || !M || !flow || !prevflow) return -1;
-    int pw = 0, ph = 0;
+    int pw = 0, ph = 0, rc = 0;
     for (int k = levels; k >= 0; k--) {
         int lw, lh, ks;
         double sigma;
         orc_level_params(w, h, k, &lw, &lh, &sigma, &ks);
         size_t n = (size_t)lw * lh;
         if (pw == 0) memset(flow, 0, sizeof(float) * 2 * n);
-        else orc_flow_upsample(prevflow, pw, ph, flow, lw, lh);
-        orc_pyr_level(prev, w, h, stride, k, I);
+        else rc |= flow_upsample_impl(ws, prevflow, pw, ph, flow, lw, lh);
+        rc |= pyr_level_impl(ws, prev, w, h, stride, k, I, flags);
         if (k == dump_level && dI0) memcpy(dI0, I, sizeof(float) * n);
-        orc_polyexp(I, lw, lh, R0);
-        orc_pyr_level(next, w, h, stride, k, I);
+        rc |= polyexp_impl(ws, I, lw, lh, R0);
+        rc |= pyr_level_impl(ws, next, w, h, stride, k, I, flags);
         if (k == dump_level && dI1) memcpy(dI1, I, sizeof(float) * n);
-        orc_polyexp(I, lw, lh, R1);
+        rc |= polyexp_impl(ws, I, lw, lh, R1);
+        if (rc) return -1;
         if (k == dump_level && dR0) memcpy(dR0, R0, sizeof(float) * 5 * n);
         if (k == dump_level && dR1) memcpy(dR1, R1, sizeof(float) * 5 * n);
         orc_update_matrices(R0, R1, flow, lw, lh, M);
@@ -490,7 +638,9 @@ ORC_API int orc_farneback_dbg(const uint8_t *prev, const uint8_t *next, int w, i
                 if (dflow) memcpy(dflow, flow, sizeof(float) * 2 * n);
                 dumped = 1;
             }
-            orc_blur_solve(M, lw, lh, flow);
+            if (flags & ORC_V_BOX_SLIDING) rc |= blur_solve_sliding_impl(ws, M, lw, lh, flow);
+            else rc |= blur_solve_impl(ws, M, lw, lh, flow);
+            if (rc) return -1;
             if (it < NUM_ITERS - 1) orc_update_matrices(R0, R1, flow, lw, lh, M);
         }
         if (k == dump_level && !dumped) {
@@ -502,12 +652,35 @@ ORC_API int orc_farneback_dbg(const uint8_t *prev, const uint8_t *next, int w, i
         ph = lh;
     }
     memcpy(flow_out, flow, sizeof(float) * 2 * N);
-    free(I); free(R0); free(R1); free(M); free(flow); free(prevflow);
+    ws_put(ws, I); ws_put(ws, R0); ws_put(ws, R1); ws_put(ws, M); ws_put(ws, flow); ws_put(ws, prevflow);
+    ws_release(ws, mark);
     return 0;
 }
 
+ORC_API int orc_farneback_dbg(const uint8_t *prev, const uint8_t *next, int w, int h, int stride, float *flow_out,
+                              int dump_level, int dump_iter, float *dI0, float *dI1, float *dR0, float *dR1,
+                              float *dM, float *dflow) {
+    return farneback_impl(0, 0, prev, next, w, h, stride, flow_out, dump_level, dump_iter, dI0, dI1, dR0, dR1, dM, dflow);
+}
+
 ORC_API int orc_farneback(const uint8_t *prev, const uint8_t *next, int w, int h, int stride, float *flow_out) {
-    return orc_farneback_dbg(prev, next, w, h, stride, flow_out, -1, 0, 0, 0, 0, 0, 0, 0);
+    return farneback_impl(0, 0, prev, next, w, h, stride, flow_out, -1, 0, 0, 0, 0, 0, 0, 0);
+}
+
+/* The same driver with the OpenCV-ordering variants of the header switched on (flags = OR of ORC_V_*): sensitivity
+ * study only -- the HIP kernels are compared with flags == 0. */
+ORC_API int orc_farneback_var(const uint8_t *prev, const uint8_t *next, int w, int h, int stride, float *flow_out,
+                              unsigned flags) {
+    return farneback_impl(0, flags, prev, next, w, h, stride, flow_out, -1, 0, 0, 0, 0, 0, 0, 0);
+}
+
+/* 1 when this library was compiled with FMA contraction (liboracle_fma.so), else 0 */
+ORC_API int orc_fma_build(void) {
+#ifdef __FP_FAST_FMA
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 /* ---- B.1 max_divergence (FunscriptFlow.pyw:748-758) ------------------------------------ */
@@ -583,6 +756,26 @@ ORC_API int orc_pair(const uint8_t *prev, const uint8_t *next, int w, int h, int
                      int *oy, float *oval, double *mean_mag) {
     int rc = orc_farneback(prev, next, w, h, stride, flow);
     if (rc) return rc;
+    orc_max_divergence(flow, w, h, ox, oy, oval);
+    *mean_mag = orc_mean_mag(flow, w, h);
+    return 0;
+}
+
+/* Workspace form for the cpu_baseline worker processes: every scratch buffer of the pair (level image, R0, R1, M, flows,
+ * blur planes, tables: ~ 90 bytes per pixel) comes out of ONE caller-owned block that the worker allocates and touches
+ * once, before the timed loop -- no malloc, no page fault and no allocator lock inside the measurement. */
+ORC_API size_t orc_ws_bytes(int w, int h) {
+    size_t N = (size_t)w * h;
+    return sizeof(float) * N * (1 + 5 + 5 + 5 + 2 + 2 + 2)   /* I, R0, R1, M, flow, prevflow, the Gaussian's tmp + blur */
+           + sizeof(double) * 16 * 5 * (size_t)w              /* column sums of a block of rows */
+           + sizeof(float) * 3 * (size_t)w + 6 * sizeof(float) * (size_t)(w + h) + 64 * 32;
+}
+
+ORC_API int orc_pair_ws(void *wsmem, size_t wsbytes, const uint8_t *prev, const uint8_t *next, int w, int h,
+                        int stride, float *flow, int *ox, int *oy, float *oval, double *mean_mag) {
+    orc_ws ws = {(char *)wsmem, wsbytes, 0, 0};
+    int rc = farneback_impl(&ws, 0, prev, next, w, h, stride, flow, -1, 0, 0, 0, 0, 0, 0, 0);
+    if (rc || ws.failed) return -2;
     orc_max_divergence(flow, w, h, ox, oy, oval);
     *mean_mag = orc_mean_mag(flow, w, h);
     return 0;

@@ -20,23 +20,59 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIB_FMA = None
+
+# variant flags of orc_farneback_var (farneback_oracle.c header): OpenCV orderings the default oracle does not reproduce
+V_BOX_SLIDING, V_AREA2X_SEQ, V_GAUSS_ROW_LTR = 1, 2, 4
+V_ALL = V_BOX_SLIDING | V_AREA2X_SEQ | V_GAUSS_ROW_LTR
 
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+def build(force=False, name="liboracle.so"):
+    so = os.path.join(_HERE, name)
     srcs = [os.path.join(_HERE, f) for f in ("farneback_oracle.c", "frontend_oracle.c")]
     if force or not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
     return so
+
+
+def cpu_has_fma():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("flags"):
+                    return " fma " in line + " "
+    except OSError:
+        pass
+    return False
+
+
+def lib_fma():
+    """The same C file built with FMA contraction (sensitivity study only); None on a host without FMA3."""
+    global _LIB_FMA
+    if _LIB_FMA is None:
+        if not cpu_has_fma():
+            return None
+        L = C.CDLL(build(name="liboracle_fma.so"))
+        L.orc_farneback_var.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_uint]
+        assert L.orc_fma_build() == 1
+        _LIB_FMA = L
+    return _LIB_FMA
 
 
 def lib():
     global _LIB
     if _LIB is None:
         L = C.CDLL(build())
+        L.orc_farneback_var.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.c_uint]
+        L.orc_pyr_level_var.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p, C.c_uint]
+        L.orc_blur_solve_sliding.argtypes = [_f32p, C.c_int, C.c_int, _f32p]
+        L.orc_ws_bytes.argtypes = [C.c_int, C.c_int]
+        L.orc_ws_bytes.restype = C.c_size_t
+        L.orc_pair_ws.argtypes = [C.c_void_p, C.c_size_t, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)]
         L.orc_num_levels.argtypes = [C.c_int, C.c_int]
         L.orc_level_params.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                        C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -197,6 +233,58 @@ def farneback(p0, p1):
     if rc:
         raise MemoryError("oracle farneback failed")
     return flow
+
+
+def farneback_var(p0, p1, flags=0, fma=False):
+    """The restatement with OpenCV-ordering variants switched on (flags = OR of V_*), optionally from the FMA-contracted
+    build.  Sensitivity study only: the HIP kernels are compared with farneback() = flags 0, no FMA."""
+    L = lib_fma() if fma else lib()
+    if L is None:
+        raise RuntimeError("this host CPU has no FMA3")
+    p0 = np.ascontiguousarray(p0, np.uint8)
+    p1 = np.ascontiguousarray(p1, np.uint8)
+    h, w = p0.shape
+    flow = np.empty((h, w, 2), np.float32)
+    if L.orc_farneback_var(p0, p1, w, h, w, flow, int(flags)):
+        raise MemoryError("oracle farneback failed")
+    return flow
+
+
+def pyr_level_var(img, k, flags):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    lw, lh, _, _ = level_params(w, h, k)
+    out = np.empty((lh, lw), np.float32)
+    lib().orc_pyr_level_var(img, w, h, w, k, out, int(flags))
+    return out
+
+
+def blur_solve_sliding(M):
+    _, h, w = M.shape
+    flow = np.empty((h, w, 2), np.float32)
+    lib().orc_blur_solve_sliding(np.ascontiguousarray(M, np.float32), w, h, flow)
+    return flow
+
+
+class PairWorkspace:
+    """Pre-faulted scratch block + output buffers for orc_pair_ws (cpu_baseline workers: nothing is allocated or
+    first-touched inside the timed loop)."""
+
+    def __init__(self, w, h):
+        self.w, self.h = w, h
+        self.nbytes = lib().orc_ws_bytes(w, h)
+        self.mem = np.zeros(self.nbytes, np.uint8)          # zeros() maps lazily: touch every page now
+        self.mem[::4096] = 1
+        self.flow = np.zeros((h, w, 2), np.float32)
+        self.flow[::64] = 1
+
+    def pair(self, p0, p1):
+        x, y, v, mm = C.c_int(), C.c_int(), C.c_float(), C.c_double()
+        rc = lib().orc_pair_ws(self.mem.ctypes.data, self.nbytes, p0, p1, self.w, self.h, self.w, self.flow,
+                               C.byref(x), C.byref(y), C.byref(v), C.byref(mm))
+        if rc:
+            raise MemoryError(f"orc_pair_ws failed ({rc})")
+        return self.flow, x.value, y.value, np.float32(v.value), mm.value
 
 
 def farneback_dbg(p0, p1, level, it):
