@@ -85,24 +85,91 @@ def alg_bytes_per_batch(N, B, U, level_sizes):
     }
 
 
-def cpu_baseline(frames, threads, pairs):
-    """Oracle (C restatement, 'port') timed on the host cores: one pair per worker, like the
-    reference's Pool(os.cpu_count()).starmap over pairs (FunscriptFlow.pyw:1190-1191)."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from concurrent.futures import ThreadPoolExecutor
-    import oracle as orc
-    orc.lib()
+def _cpu_worker(frames, w, h, jobs, barrier, q):
+    """One worker PROCESS of the cpu_baseline pool (forked before any GPU call): its own pre-faulted workspace, so the
+    timed loop neither mallocs nor first-touches a page; starts on a barrier shared by the whole pool."""
+    try:
+        import oracle as orc
+        ws = orc.PairWorkspace(w, h)
+        n = len(frames) - 1
+        barrier.wait(timeout=300)
+        t0 = time.perf_counter()              # CLOCK_MONOTONIC: comparable across the pool's processes
+        for j in jobs:
+            flow, x, y, v, mm = ws.pair(frames[j % n], frames[j % n + 1])
+            orc.radial_c(flow, (w / 2.0, h / 2.0), mm > 7, False)
+        q.put((t0, time.perf_counter(), len(jobs)))
+    except BaseException as e:  # noqa: BLE001
+        q.put(("error", repr(e), 0))
+
+
+def _cpu_pool_rate(frames, workers, pairs_per_worker):
+    """pairs/s of `workers` processes x `pairs_per_worker` pairs each: all pairs / (last end - first start)."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
     h, w = frames[0].shape
+    barrier, q = ctx.Barrier(workers), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, daemon=True,
+                         args=(frames, w, h, [i * pairs_per_worker + k for k in range(pairs_per_worker)], barrier, q))
+             for i in range(workers)]
+    for p in procs:
+        p.start()
+    got = []
+    try:
+        for _ in procs:
+            r = q.get(timeout=600)
+            if r[0] == "error":
+                raise RuntimeError(f"cpu_baseline worker failed: {r[1]}")
+            got.append(r)
+    finally:
+        for p in procs:
+            p.join(timeout=5)
+            if p.is_alive():
+                p.kill()
+    t0, t1 = min(g[0] for g in got), max(g[1] for g in got)
+    return sum(g[2] for g in got) / (t1 - t0), t1 - t0
 
-    def one(j):
-        flow, x, y, v, mm = orc.pair_c(frames[j % (len(frames) - 1)], frames[j % (len(frames) - 1) + 1])
-        return orc.radial_c(flow, (w / 2.0, h / 2.0), mm > 7, False)
 
-    t0 = time.perf_counter()
-    with ThreadPoolExecutor(threads) as ex:
-        list(ex.map(one, range(pairs)))
-    dt = time.perf_counter() - t0
-    return pairs / dt, dt
+def cpu_baseline(frames, max_workers=None, pairs_per_worker=2):
+    """The reference's CPU path as a stated baseline: a pool of PROCESSES over pairs (FunscriptFlow.pyw:1190-1191,
+    Pool(processes=threads).starmap), each running the C oracle ('port': Farneback + argmax + mean magnitude + radial) on
+    the same synthetic stream.  MUST run before the first HIP call of this process (fork is only safe then): main() calls
+    it before `import torch`.  Measures 1 worker, then 16 / 64 / os.cpu_count() workers (those that fit) so that the knee
+    is visible; `value` is the best point of the sweep."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as orc
+    orc.lib()                                   # build + load once, the workers inherit it
+    h, w = frames[0].shape
+    cores = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = cores
+    per_worker = orc.lib().orc_ws_bytes(w, h) + 8 * w * h
+    try:
+        import psutil
+        fit = max(1, int(psutil.virtual_memory().available * 0.5 // per_worker))
+    except Exception:  # noqa: BLE001
+        fit = cores
+    top = min(max_workers or cores, cores, fit)
+    single, sdt = _cpu_pool_rate(frames, 1, max(pairs_per_worker, 2))
+    sweep = {"1": {"pairs_per_s": single, "per_worker": single, "wall_s": sdt}}
+    for n in sorted({min(16, top), min(64, top), top}):
+        if n <= 1:
+            continue
+        v, dt = _cpu_pool_rate(frames, n, pairs_per_worker)
+        sweep[str(n)] = {"pairs_per_s": v, "per_worker": v / n, "wall_s": dt}
+    best = max(sweep, key=lambda k: sweep[k]["pairs_per_s"])
+    full = sweep[str(top)] if str(top) in sweep else sweep[best]
+    return {"value": sweep[best]["pairs_per_s"], "unit": "pairs/s", "cores": int(best), "kind": "port",
+            "host_cores": cores, "usable_cores": usable, "single_thread": single,
+            "full_width": {"workers": top, "pairs_per_s": full["pairs_per_s"], "per_worker": full["per_worker"],
+                           "per_worker_vs_single": full["per_worker"] / single},
+            "sweep": sweep,
+            "sample": f"{w}x{h} pairs of the same synthetic stream; a pool of worker PROCESSES as the reference's "
+                      f"Pool(processes=threads).starmap (FF:1190-1191), forked before any GPU call, one pre-faulted workspace "
+                      f"per worker (no malloc / page fault in the timed loop), {pairs_per_worker} pairs per worker, barrier "
+                      f"start; C oracle (Farneback + argmax + mean magnitude + radial); `value` = best point of the sweep "
+                      f"({best} workers), `cores` = its worker count; total {sum(v['wall_s'] for v in sweep.values()):.1f} s wall"}
 
 
 class StepRunner:
@@ -196,9 +263,12 @@ def verify(runner, frames, W, H, B, seed, ctx):
     return golden_check.check_batch(gold, frames, recs, dots, lambda j: ctx.download_flow(slots[j]))
 
 
-def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None):
-    """Host numpy frames -> per-pair scalars through pipeline.PairEngine: every frame crosses PCIe once (pinned
-    staging copy + hipMemcpyAsync on the copy stream, overlapped with the previous batches' kernels)."""
+def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None, pinned=False):
+    """Host frames -> per-pair scalars through pipeline.PairEngine: every frame crosses PCIe once, on the copy stream,
+    overlapped with the previous batches' kernels.  pinned = False: pageable ndarrays (what cv2.VideoCapture.read hands
+    Python, FF:178), copied into the context's pinned staging first; pinned = True: the frames already lie in page-locked
+    memory of the context (Context.pinned_frames = ffl_host_alloc, where prefetch.PrefetchRing makes the decoder write
+    them), so the H2D transfer starts straight out of them -- no staging copy."""
     from funscript_flow_amd import _capi, pipeline
     from funscript_flow_amd.synth import gray_to_bgr, sine_translate_frames
     if base is None:
@@ -206,16 +276,129 @@ def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None):
     base = base[:17]                                  # one period of the clip, cycled
     if bgr:
         base = gray_to_bgr(base)
-    frames = [base[i % len(base)] for i in range(n_frames)]
     with _capi.Context(W, H, device=device, max_batch=B, frame_slots=2 * B + 2, flow_slots=pipeline.min_flow_slots(B)) as ctx:
+        if pinned:
+            store = ctx.pinned_frames(n_frames, 3 if bgr else 1)
+            for i in range(n_frames):
+                store[i] = base[i % len(base)]          # the "decoder" writes into page-locked memory, outside the timed region
+            frames = [store[i] for i in range(n_frames)]
+        else:
+            frames = [base[i % len(base)] for i in range(n_frames)]
         eng = pipeline.PairEngine(ctx)
         eng.process_chunk(frames[:2 * B + 1])  # warm-up
         t0 = time.perf_counter()
         eng.process_chunk(frames)
         dt = time.perf_counter() - t0
+        frames = store = None
     n = n_frames - 1
-    return {"value": n / dt, "unit": "pairs/s", "pairs": n, "input": "BGR uint8 ndarrays" if bgr else "gray uint8 ndarrays",
+    return {"value": n / dt, "unit": "pairs/s", "pairs": n,
+            "input": ("BGR" if bgr else "gray") + (" uint8 frames in page-locked host memory (ffl_host_alloc), no staging copy" if pinned
+                                                   else " uint8 pageable ndarrays, staged through pinned memory"),
             "h2d_GBps": n / dt * W * H * (3 if bgr else 1) / 1e9, "pairs_per_batch": B}
+
+
+def load_traffic(W, H, B, kernel):
+    """PMC traffic of `kernel` for this workload from profiles/traffic.json (one entry per workload, each tied to the
+    signature of the device sources it was measured on): (bytes per launch or None, note)."""
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(tpath):
+        return None, "profiles/traffic.json absent"
+    try:
+        tj = json.load(open(tpath))
+        e = tj.get("workloads", {}).get(f"{W}x{H}_b{B}")
+        if e is None or e.get("kernel") != kernel:
+            return None, f"profiles/traffic.json has no {kernel} entry for {W}x{H} B={B}"
+        if e.get("kernel_signature") != kernel_signature():
+            return None, (f"profiles/traffic.json entry is stale: measured on kernels {e.get('kernel_signature')}, this build is "
+                          f"{kernel_signature()} (re-run profiles/tools/capture_round.sh)")
+        if e.get("fuse_first", 10000) != FUSE_FIRST:
+            return None, "profiles/traffic.json entry was measured with another fuse_first"
+        return e.get("hbm_bytes_per_launch"), (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload on kernels "
+                                               f"{e.get('kernel_signature')} ({e.get('captured', '?')}); 2 x FETCH + WRITE, KiB")
+    except Exception as ex:  # noqa: BLE001
+        return None, f"profiles/traffic.json unreadable: {ex}"
+
+
+def roofline_block(prof, alg, steps, W, H, B, kernel=None):
+    """The `roofline` object for the dominant kernel class of a pass timed with HIP events."""
+    dom = kernel or max((k for k in alg), key=lambda k: prof[k][1])
+    n_launch, ms = prof[dom]
+    achieved = alg[dom] * steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    avg_ms = ms / max(n_launch, 1)
+    traffic, note = load_traffic(W, H, B, dom)
+    return {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / PEAK_GBPS, "traffic": traffic,
+            "frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_GBPS) if traffic and avg_ms > 0 else None,
+            "traffic_note": note, "launches": n_launch, "avg_launch_ms": avg_ms,
+            "alg_bytes_per_launch": alg[dom] * steps / max(n_launch, 1)}
+
+
+def large_image(W, H, B, steps, warmup, device, seed, what):
+    """A second resident workload in the same line (configs[2] 3840x2160, the configs[4] eye 2880x2880): pairs/s, the
+    dominant kernel's roofline from HIP events in the timed region, `checked` against the oracle golden."""
+    dt, prof, run, fr, lv, U, ctx = resident_pass(W, H, B, steps, warmup, device, seed, [DOMINANT])
+    chk = verify(run, fr, W, H, B, seed, ctx)
+    ctx.close()
+    alg = alg_bytes_per_batch(W * H, B, U, lv)
+    return {"workload": what, "pairs_per_step": B, "steps": steps, "value": steps * B / dt, "unit": "pairs/s",
+            "ms_per_step": dt / steps * 1e3, "roofline": roofline_block(prof, alg, steps, W, H, B, DOMINANT),
+            "whole_path_frac": sum(alg.values()) * steps / dt / 1e9 / PEAK_GBPS,
+            "checked": chk[0], "check_detail": chk[1]}
+
+
+def one_clip(args, rank, world, local_rank, host_group, barrier, torch, dist):
+    """north_star's wording: the pairs of ONE clip dealt round-robin over the GPUs (strong scaling of a chunk).
+
+    The clip is steps x batch x N pairs of the seed-1 stream (host ndarrays: 17 distinct frames, cycled); every rank runs
+    pipeline.process_chunk_sharded -- pass 1 on its blocks of --rr-block pairs (a block of b pairs uploads and expands
+    b + 1 frames), host all-gather of the 32-byte pass-1 records (gloo), centres smoothed over the whole clip, pass 2 on
+    the owning rank, host all-gather of the scalars.  Frames cross PCIe inside the timed region, so this is a
+    PCIe-inclusive figure; `value` = pairs of the clip / max-over-ranks time."""
+    from funscript_flow_amd import _capi, pipeline
+    from funscript_flow_amd.synth import sine_translate_frames
+    W, H, B = args.width, args.height, args.batch
+    n_pairs = args.steps * B * world
+    base = sine_translate_frames(17, W, H, seed=1)
+    frames = [base[i % 16] for i in range(n_pairs + 1)]        # period 16: frame 16 == frame 0 (the same array object)
+    mine = pipeline.shard_pairs(n_pairs, world, rank, args.assign, args.rr_block)
+    _capi.set_option("lanes", args.lanes or 2)
+
+    def allgather(obj):
+        if world == 1:
+            return [obj]
+        out = [None] * world
+        dist.all_gather_object(out, obj, group=host_group)
+        return out
+
+    with _capi.Context(W, H, device=local_rank, max_batch=B, frame_slots=2 * B + 2, flow_slots=max(len(mine), 1)) as ctx:
+        eng = pipeline.HipShardEngine(ctx)
+        warm = frames[:min(n_pairs, 2 * B * world) + 1]
+        pipeline.process_chunk_sharded(eng, warm, rank, world, allgather, assign=args.assign, block=args.rr_block)
+        barrier()
+        t0 = time.perf_counter()
+        dots, recs = pipeline.process_chunk_sharded(eng, frames, rank, world, allgather, assign=args.assign, block=args.rr_block)
+        barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        # the stream has period 16: pair j and pair j + 16 are the same images, and (away from the clip's ends, where the
+        # smoothing window is clipped) have the same centre -> the same scalar, whichever rank computed them
+        ok = all(tuple(recs[j]) == tuple(recs[j + 16]) for j in range(n_pairs - 16)) and \
+            all(dots[j] == dots[j + 16] for j in range(6, n_pairs - 22))
+        _emit(json.dumps({
+            "metric": "1080p frame-pairs/sec" if (W, H) == (1920, 1080) else f"{W}x{H} frame-pairs/sec",
+            "mode": "one_clip", "value": n_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": 1,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "checked": bool(ok),
+            "check_detail": "period-16 property over the gathered records and scalars (same images on different ranks give the same bits)",
+            "config": {"workload": f"ONE {W}x{H} clip of {n_pairs} pairs from host ndarrays (uploads inside the timed region), "
+                                   f"pairs dealt {args.assign} in blocks of {args.rr_block} over {world} GPU(s)",
+                       "pairs_per_step": B, "parallelism": f"pair-shard x{world} ({args.assign}, block {args.rr_block})",
+                       "compute_lanes": args.lanes or 2, "exchange": "host all-gather (gloo) of 32 B per pair after pass 1, 16 B after pass 2",
+                       "kernel_signature": kernel_signature()}}))
 
 
 _REAL_STDOUT = None
@@ -250,7 +433,8 @@ def main():
                          "1080p 4450 / 4700 / 5030 / 4880 pairs/s at B = 8 / 16 / 32 / 64")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the kernel_classes / pcie_inclusive / small_image passes")
-    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs in the CPU sample (default: one per thread, >= 32)")
+    ap.add_argument("--cpu-pairs", type=int, default=0, help="pairs per worker process of the CPU sample (default 2)")
+    ap.add_argument("--cpu-workers", type=int, default=0, help="widest pool of the cpu_baseline sweep (default os.cpu_count())")
     ap.add_argument("--independent", action="store_true", help="2B frames per batch (no frame sharing)")
     ap.add_argument("--zoom", type=float, default=0.0,
                     help="breathing zoom of the synthetic clip (0 = BASELINE's pure sine-translate); a zooming clip has a "
@@ -268,6 +452,12 @@ def main():
                          "1 run-ahead, the chain waits per level")
     ap.add_argument("--rehearse-gloo", action="store_true",
                     help="N>1 rehearsal on a 1-GPU box: every rank uses cuda:0 and the process group is gloo")
+    ap.add_argument("--one-clip", action="store_true",
+                    help="strong-scaling form (north_star: 'frame-pairs sharded round-robin across GPUs'): ONE clip of "
+                         "steps x batch x N pairs, dealt to the ranks in blocks of --rr-block pairs by "
+                         "pipeline.process_chunk_sharded (host frames, uploads included); beside, never instead of, the default")
+    ap.add_argument("--rr-block", type=int, default=8, help="--one-clip: pairs per round-robin block (1 = pair by pair)")
+    ap.add_argument("--assign", default="round_robin", choices=["round_robin", "contiguous"], help="--one-clip: pair assignment")
     ap.add_argument("--no-events", action="store_true", help="diagnostic: no per-kernel HIP events (roofline omitted)")
     ap.add_argument("--profile-all", action="store_true",
                     help="HIP events around every kernel class in the TIMED region (adds ~0.2 ms/step); default: the "
@@ -282,6 +472,23 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
 
+    W, H, B = args.width, args.height, args.batch
+    N = W * H
+    seed = 1 if world == 1 else 10 + rank
+
+    # The CPU baseline is a pool of forked worker processes (the reference's Pool, FF:1190-1191): it runs FIRST, before
+    # torch / HIP are loaded -- never fork a process that has initialised the GPU.  Under rocprofv3 the profiler's preloaded
+    # library has already done that, so the leg is skipped there (the capture scripts pass --no-cpu-baseline anyway).
+    from funscript_flow_amd.synth import sine_translate_frames
+    frames0 = None
+    cpu_base = None
+    if world == 1 and rank == 0 and not args.no_cpu_baseline:
+        if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+            cpu_base = {"value": None, "skipped": "running under rocprofv3: the GPU is already initialised, no fork"}
+        else:
+            frames0 = sine_translate_frames((2 * B if args.independent else B + 1), W, H, seed=seed, zoom=args.zoom)
+            cpu_base = cpu_baseline(frames0[:17], max_workers=args.cpu_workers or None, pairs_per_worker=args.cpu_pairs or 2)
+
     import torch  # first: its HIP runtime (same SONAME) is the one libffl_hip.so binds to
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -292,12 +499,30 @@ def main():
     host_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        import datetime
         if args.rehearse_gloo:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
             host_group = dist.group.WORLD
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-            host_group = dist.new_group(backend="gloo")
+            # RCCL carries only the contract's barrier / MAX (no data-path collective).  Bring the communicator up NOW, with
+            # a real collective on the device, so that a broken RCCL / xGMI setup ends the run with one clear message and a
+            # non-zero exit code before anything is timed -- never a silent switch to another backend.
+            try:
+                if torch.cuda.device_count() <= local_rank:
+                    raise RuntimeError(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} visible GPUs")
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
+                                        timeout=datetime.timedelta(seconds=300))
+                probe = torch.ones(1, device="cuda") * (rank + 1)
+                dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+                torch.cuda.synchronize()
+                if int(probe.item()) != world * (world + 1) // 2:
+                    raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
+                host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
+            except Exception as e:  # noqa: BLE001
+                print(f"bench.py: FATAL rank {rank}/{world}: the RCCL ('nccl') process group did not come up on cuda:{local_rank}: "
+                      f"{type(e).__name__}: {e}\nbench.py: no number is reported; there is no fallback backend for N > 1 "
+                      f"(use --rehearse-gloo only for single-GPU rehearsals)", file=sys.stderr, flush=True)
+                os._exit(3)
 
     from funscript_flow_amd import _capi
 
@@ -314,9 +539,6 @@ def main():
     # rocprofv3's).  `--lanes 2` (the library's default for production use) co-schedules two batches.
     _capi.set_option("lanes", args.lanes or 1)
     _capi.set_option("run_ahead", args.expand)
-    W, H, B = args.width, args.height, args.batch
-    N = W * H
-    seed = 1 if world == 1 else 10 + rank
 
     def barrier():
         torch.cuda.synchronize()
@@ -324,9 +546,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.one_clip:
+        one_clip(args, rank, world, local_rank, host_group, barrier, torch, dist)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     events = False if args.no_events else (True if args.profile_all else [DOMINANT])
     dt, prof, runner, frames, level_sizes, U, ctx = resident_pass(
-        W, H, B, args.steps, args.warmup, local_rank, seed, events, args.independent, args.zoom, barrier, args.trace_steps)
+        W, H, B, args.steps, args.warmup, local_rank, seed, events, args.independent, args.zoom, barrier, args.trace_steps,
+        frames=frames0)
     if runner.trace:
         d = np.diff(np.array(runner.trace[-args.steps:])) * 1e3
         print("step ms:", " ".join(f"{v:.2f}" for v in d), file=sys.stderr)
@@ -354,28 +584,7 @@ def main():
     if rank == 0:
         pairs = world * args.steps * B
         alg = alg_bytes_per_batch(N, B, U, level_sizes)
-        dom = max((k for k in alg), key=lambda k: prof[k][1])
-        n_launch, ms = prof[dom]
-        achieved = alg[dom] * args.steps / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
-        avg_ms = ms / max(n_launch, 1)
-        traffic, traffic_note = None, "profiles/traffic.json absent"
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("workload") != f"{W}x{H}" or tj.get("batch") != B or tj.get("kernel") != dom:
-                    traffic_note = "profiles/traffic.json was measured on another workload"
-                elif tj.get("kernel_signature") != kernel_signature():
-                    traffic_note = (f"profiles/traffic.json is stale: measured on kernels {tj.get('kernel_signature')}, "
-                                    f"this build is {kernel_signature()} (re-run profiles/tools/capture_round.sh)")
-                elif tj.get("fuse_first", 10000) != FUSE_FIRST:
-                    traffic_note = "profiles/traffic.json was measured with another fuse_first"
-                else:
-                    traffic = tj.get("hbm_bytes_per_launch")
-                    traffic_note = (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on kernels "
-                                    f"{tj.get('kernel_signature')} ({tj.get('captured', '?')}); 2 x FETCH + WRITE, KiB")
-            except Exception as e:  # noqa: BLE001
-                traffic_note = f"profiles/traffic.json unreadable: {e}"
+        roof = roofline_block(prof, alg, args.steps, W, H, B)
         out = {
             "metric": "1080p frame-pairs/sec" if (W, H) == (1920, 1080) else f"{W}x{H} frame-pairs/sec",
             "value": pairs / dt,
@@ -395,12 +604,7 @@ def main():
                        "pairs_per_step": B, "frames_per_step": U, "levels": len(level_sizes), "winsize": 15, "iterations": 3,
                        "poly_n": 5, "parallelism": f"pair-shard x{world}", "compute_lanes": args.lanes or 1,
                        "kernel_signature": kernel_signature()},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / PEAK_GBPS, "traffic": traffic,
-                         "frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / PEAK_GBPS) if traffic and avg_ms > 0 else None,
-                         "traffic_note": traffic_note,
-                         "launches": n_launch, "avg_launch_ms": avg_ms,
-                         "alg_bytes_per_launch": alg[dom] * args.steps / max(n_launch, 1)},
+            "roofline": roof,
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
             "whole_path": {"alg_bytes_per_pair": sum(alg.values()) / B,
                            "achieved_GBps": sum(alg.values()) / B * (pairs / world) / dt / 1e9},
@@ -411,7 +615,15 @@ def main():
             ksteps = max(3, min(args.steps, 6))
             kdt, kprof, _, _, _, _, kctx = resident_pass(W, H, B, ksteps, 1, local_rank, seed, True, args.independent, args.zoom,
                                                           frames=frames, depth=0)
+            # k_gray (BGR -> gray at upload, 3N in + 1N out per frame: the 8N per pair of SURVEY's B_alg) never runs on resident
+            # gray frames: time it here on one BGR upload of the batch's frames (events bracket the kernel, not the H2D copy)
+            from funscript_flow_amd.synth import gray_to_bgr
+            kctx.profile_enable(["k_gray"])
+            kctx.upload_frames(0, list(gray_to_bgr(frames[:U])))
+            gprof = kctx.profile_read()["k_gray"]
             kctx.close()
+            alg = dict(alg, k_gray=4.0 * N * U)
+            kprof["k_gray"] = (gprof[0] * ksteps, gprof[1] * ksteps)   # per-step figures below divide by ksteps
             out["kernel_classes"] = {
                 k: {"ms_per_step": v[1] / ksteps, "launches_per_step": v[0] / ksteps,
                     "alg_bytes_per_step": alg.get(k), "frac": (alg[k] / (v[1] / ksteps * 1e-3) / 1e9 / PEAK_GBPS) if k in alg and v[1] > 0 else None}
@@ -424,7 +636,12 @@ def main():
             pbase = frames if (len(frames) >= 17 and not args.independent and args.zoom == 0.0) else None
             out["pcie_inclusive"] = {"gray": pcie_inclusive(W, H, B, local_rank, seed, nfr, False, pbase),
                                      "bgr": pcie_inclusive(W, H, B, local_rank, seed, nfr, True, pbase),
-                                     "note": "pipeline.PairEngine, 2 compute lanes, pageable ndarrays copied into pinned staging"}
+                                     "bgr_pinned": pcie_inclusive(W, H, B, local_rank, seed, nfr, True, pbase, pinned=True),
+                                     "note": "pipeline.PairEngine, 2 compute lanes; gray / bgr: pageable ndarrays copied into "
+                                             "pinned staging by the library; bgr_pinned: frames already in ffl_host_alloc memory "
+                                             "(the prefetch ring's zero-copy path)"}
+            for k in ("gray", "bgr", "bgr_pinned"):
+                out["pcie_inclusive"][k]["vs_resident"] = out["pcie_inclusive"][k]["value"] / out["value"]
             _capi.set_option("lanes", args.lanes or 1)
             # (3) the reference's own operating point (FF:1057: every frame is resized to 256x256 first)
             if (W, H) != (256, 256):
@@ -445,21 +662,22 @@ def main():
                                       "checked": schk[0], "check_detail": schk[1]}
                 _capi.set_option("lanes", 2)
                 out["small_image"]["pcie_inclusive_gray"] = pcie_inclusive(256, 256, SB, local_rank, 1, 8 * SB + 1, False, sfr)
+                _capi.set_option("lanes", 1)
+                # the dominant kernel's own roofline at this size: a short pass with HIP events (eager launches, one lane)
+                edt, eprof, _, _, _, _, ectx = resident_pass(256, 256, SB, 10, 2, local_rank, 1, [DOMINANT], frames=sfr)
+                ectx.close()
+                out["small_image"]["roofline"] = roofline_block(eprof, salg, 10, 256, 256, SB, DOMINANT)
                 _capi.set_option("lanes", args.lanes or 1)
-        if world == 1 and not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
-            threads = cores                              # the reference: Pool(os.cpu_count()) over pairs, FF:1190
-            npairs = args.cpu_pairs or max(threads, 32)  # one pair per worker: ~0.6 s per 1080p pair and core
-            v, cdt = cpu_baseline(frames, threads, npairs)
-            try:
-                usable = len(os.sched_getaffinity(0))
-            except AttributeError:
-                usable = cores
-            out["cpu_baseline"] = {"value": v, "unit": "pairs/s", "cores": cores, "threads": threads, "usable_cores": usable,
-                                   "kind": "port",
-                                   "sample": f"{npairs} pairs of the same {W}x{H} stream, one pair per worker thread, "
-                                             f"{threads} threads = os.cpu_count() as the reference's Pool (FF:1190), "
-                                             f"C oracle (Farneback + argmax + mean + radial), {cdt:.1f} s wall"}
+            # (4) the large configurations: configs[2] (3840x2160) and one eye of configs[4] (2880x2880), resident, one lane
+            if (W, H) == (1920, 1080) and not args.independent and args.zoom == 0.0:
+                _capi.set_option("lanes", 1)
+                out["large_image"] = {
+                    "3840x2160": large_image(3840, 2160, 32, 10, 2, local_rank, 1, "BASELINE configs[2]: 3840x2160 stream, gray frames resident"),
+                    "2880x2880_eye": large_image(2880, 2880, 32, 10, 2, local_rank, 2,
+                                                 "BASELINE configs[4] unit: one 2880x2880 eye of a 5760x2880 stereo stream, gray frames resident")}
+                _capi.set_option("lanes", args.lanes or 1)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         _emit(json.dumps(out))
     if world > 1:
         dist.barrier()

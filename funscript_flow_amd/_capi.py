@@ -19,7 +19,7 @@ EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "f
            "ffl_flow_pairs",
            "ffl_pass1_result", "ffl_pass1_results", "ffl_radial", "ffl_download_flow", "ffl_upload_flow", "ffl_submit_pair", "ffl_sync",
            "ffl_num_levels", "ffl_level_size", "ffl_download_frame", "ffl_debug_pair", "ffl_set_option", "ffl_profile_enable",
-           "ffl_profile_read", "ffl_kernel_name"]
+           "ffl_profile_read", "ffl_kernel_name", "ffl_device_mem_info", "ffl_estimate_bytes"]
 
 
 class FFLError(RuntimeError):
@@ -70,6 +70,8 @@ def load():
     L.ffl_kernel_name.argtypes = [C.c_int]
     L.ffl_kernel_name.restype = C.c_char_p
     L.ffl_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.ffl_device_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.ffl_estimate_bytes.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -82,6 +84,24 @@ def set_option(name, value):
 
 def device_count():
     return load().ffl_device_count()
+
+
+def device_mem_info(device=0):
+    """(free, total) bytes of device memory (hipMemGetInfo)."""
+    f, t = C.c_size_t(), C.c_size_t()
+    L = load()
+    if L.ffl_device_mem_info(int(device), C.byref(f), C.byref(t)) != FFL_OK:
+        raise FFLError(f"ffl_device_mem_info failed: {L.ffl_last_error(None).decode()}")
+    return f.value, t.value
+
+
+def estimate_bytes(width, height, frame_slots, flow_slots, max_batch):
+    """(device, pinned host) bytes a Context with these arguments allocates under the current "lanes" option."""
+    d, p = C.c_size_t(), C.c_size_t()
+    L = load()
+    if L.ffl_estimate_bytes(int(width), int(height), int(frame_slots), int(flow_slots), int(max_batch), C.byref(d), C.byref(p)) != FFL_OK:
+        raise FFLError(f"ffl_estimate_bytes failed: {L.ffl_last_error(None).decode()}")
+    return d.value, p.value
 
 
 def _iarr(v):

@@ -132,23 +132,40 @@ def radial_motion_weighted(flow, center, is_cut, pov_mode=False, device=0):
 _chunk_ctx = {}
 
 
+def _fit_chunk(width, height, n_pairs, device, max_batch, reclaim=0):
+    """Largest batch size <= max_batch whose context (the chunk's flows resident + the lanes' work buffers, which
+    scale with the batch) fits the device's FREE memory (hipMemGetInfo through the C ABI; `reclaim` = bytes a context
+    about to be closed gives back).  Raises with the numbers when even B = 1 does not fit."""
+    free, total = _capi.device_mem_info(device)
+    budget = (free + reclaim) * 0.95
+    B = max_batch
+    while True:
+        need, pinned = _capi.estimate_bytes(width, height, 2 * B + 2, max(n_pairs, 1), B)
+        if need <= budget:
+            return B, need
+        if B == 1:
+            flows = 8.0 * width * height * n_pairs
+            raise _capi.FFLError(
+                f"a chunk of {n_pairs} pairs at {width}x{height} needs {need / 1e9:.1f} GB on the device ({flows / 1e9:.1f} GB of "
+                f"resident flow fields), {budget / 1e9:.1f} GB are free: lower batch_size (FF:2647) or use "
+                "pipeline.PairEngine, which recycles flow slots (2B + 13 resident fields)")
+        B = max(1, B // 2)
+
+
 def _chunk_context(width, height, n_pairs, device, max_batch):
     """A context whose flow slots hold a whole chunk (the reference keeps `precomputed`, flows included, for the
-    chunk: FF:1191-1236) -- grown on demand, reused across chunks."""
+    chunk: FF:1191-1236) -- grown on demand, reused across chunks, sized against the device's free memory."""
     key = (width, height, device)
     ctx = _chunk_ctx.get(key)
-    if ctx is None or ctx.flow_slots < n_pairs or ctx.max_batch != max_batch:
+    if ctx is None or ctx.flow_slots < n_pairs or ctx._asked_batch != max_batch:
         serial = getattr(ctx, "_chunk_serial", 0)
+        reclaim = _capi.estimate_bytes(width, height, ctx.frame_slots, ctx.flow_slots, ctx.max_batch)[0] if ctx is not None else 0
+        B, _ = _fit_chunk(width, height, n_pairs, device, max_batch, reclaim)   # raises before the old context is given up
         if ctx is not None:
             ctx.close()
             _chunk_ctx.pop(key, None)
-        need = 8.0 * width * height * n_pairs
-        if need > 200e9:
-            raise _capi.FFLError(f"a chunk of {n_pairs} pairs at {width}x{height} needs {need / 1e9:.0f} GB of resident flow: "
-                                 "lower batch_size (FF:2647) or use pipeline.PairEngine, which recycles flow slots")
-        ctx = _capi.Context(width, height, device=device, frame_slots=2 * max_batch + 2,
-                            flow_slots=max(n_pairs, 1), max_batch=max_batch)
-        ctx._chunk_serial = serial
+        ctx = _capi.Context(width, height, device=device, frame_slots=2 * B + 2, flow_slots=max(n_pairs, 1), max_batch=B)
+        ctx._chunk_serial, ctx._asked_batch = serial, max_batch
         _chunk_ctx[key] = ctx
     ctx._chunk_serial += 1
     return ctx
@@ -174,6 +191,7 @@ def precompute_all(pairs, params):
     h, w = pairs[0][0].shape[:2]
     B = max(1, min(int(params.get("hip_batch", 32)), _capi.FFL_MAX_BATCH))
     ctx = _chunk_context(w, h, len(pairs), int(params.get("device", 0)), B)
+    B = ctx.max_batch                       # possibly smaller than asked for: what fits beside the chunk's flows
     # frames of the chunk in order of first use; a pair's two operands become frame indices
     frames, index = [], {}
     idx = []

@@ -229,11 +229,17 @@ struct ffl_ctx {
     int prof_launches[FFL_K_COUNT] = {0};
     double prof_ms[FFL_K_COUNT] = {0};
     std::string err;
-    // Every entry point takes this lock, so calls from several host threads are safe; the calls that wait for the
-    // device (ffl_pass1_result, ffl_download_flow) drop it while they wait, so a thread collecting results does
-    // not hold up another one that is uploading frames or queueing the next batch (submit / pass1 /
-    // radial on distinct slots may come from different host threads).
-    std::recursive_mutex mu;
+    // Every entry point takes this lock, so calls from several host threads are safe.  NO call holds it while it waits
+    // for the device or copies frames: ffl_pass1_result, ffl_download_flow, ffl_radial, ffl_upload_flow, ffl_sync and
+    // ffl_host_free drop it around their waits, ffl_upload_frames(_raw) around the staging memcpy -- so a thread
+    // collecting results does not hold up another one that is uploading frames or queueing the next batch (SURVEY 8b:
+    // submit / pass1 / radial on distinct slots may come from different host threads).
+    // Two small locks order the users of shared single-copy resources among themselves; both are taken BEFORE `mu`:
+    //   up_mu    uploaders: the per-slot staging areas, the copy pool and the raw-frame ring
+    //   post_mu  users of stream `post` and its single pinned tables / result buffer (ffl_radial, ffl_upload_flow)
+    mutable std::recursive_mutex mu;
+    std::mutex up_mu, post_mu;
+    int graph_bad_epoch = -1;  // option epoch in which a graph capture failed: batches launch eagerly until it changes
 };
 typedef std::unique_lock<std::recursive_mutex> CtxLock;
 
@@ -431,7 +437,15 @@ int ffl_device_count(void) {
     return n;
 }
 
-const char *ffl_last_error(const ffl_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+const char *ffl_last_error(const ffl_ctx *ctx) {
+    if (!ctx) return g_create_error.c_str();
+    // copied under the lock into a per-thread buffer: another thread's failing call may replace ctx->err while the caller
+    // still reads the text (valid until this thread's next ffl_last_error call)
+    static thread_local std::string copy;
+    CtxLock lk(ctx->mu);
+    copy = ctx->err;
+    return copy.c_str();
+}
 
 const char *ffl_kernel_name(int k) {
     static const char *names[FFL_K_COUNT] = {"k_gray",  "k_pyr_level", "k_polyexp", "k_frontend",
@@ -599,6 +613,45 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     return FFL_OK;
 }
 
+int ffl_device_mem_info(int device, size_t *free_bytes, size_t *total_bytes) {
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return set_err(nullptr, FFL_ERR_NO_DEVICE, "ffl_device_mem_info: no HIP device available");
+    if (device < 0 || device >= ndev) return set_err(nullptr, FFL_ERR_INVALID, "ffl_device_mem_info: device %d out of range", device);
+    size_t f = 0, t = 0;
+    if (hipSetDevice(device) != hipSuccess || hipMemGetInfo(&f, &t) != hipSuccess)
+        return set_err(nullptr, FFL_ERR_HIP, "ffl_device_mem_info: hipMemGetInfo failed");
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return FFL_OK;
+}
+
+// What ffl_create(width, height, n_frame_slots, n_flow_slots, max_batch) allocates with the current "lanes" option: the
+// same sums as the hipMalloc / hipHostMalloc calls above (small tables rounded up to 1 MiB in total).  No device needed.
+int ffl_estimate_bytes(int width, int height, int n_frame_slots, int n_flow_slots, int max_batch, size_t *device_bytes,
+                       size_t *pinned_bytes) {
+    if (width < 16 || height < 16 || (long)width * height * 20 >= (1L << 32) || n_frame_slots < 2 || n_flow_slots < 1 ||
+        max_batch < 1 || max_batch > FFL_MAX_BATCH)
+        return set_err(nullptr, FFL_ERR_INVALID, "ffl_estimate_bytes: bad geometry / slot counts");
+    ffl_ctx g;  // geometry only
+    g.w = width;
+    g.h = height;
+    level_geometry(&g);
+    const size_t N = (size_t)width * height, maxU = 2 * (size_t)max_batch;
+    size_t lane = 0;
+    for (int k = 0; k <= g.levels; k++) {
+        const size_t n = (size_t)g.geom[k].lw * g.geom[k].lh;
+        lane += sizeof(float) * maxU * (ffl_pyr_tmp_floats(width, height, g.geom[k].lw) + 5 * n + n);  // T, R, I
+    }
+    lane += sizeof(float) * N * max_batch * (5 + 5 + 2 + 2);                                            // M x 2, flow A / B
+    lane += (size_t)ffl_pass1_blocks(width, height) * max_batch * 16;
+    size_t dev = (size_t)g_num_lanes * lane + (size_t)n_frame_slots * N * 4 + sizeof(float) * 2 * N * n_flow_slots + ((size_t)1 << 20);
+    size_t pin = (size_t)n_frame_slots * N * 4 + sizeof(Pass1Result) * n_flow_slots + (size_t)g_num_lanes * sizeof(BatchTab) * FFL_EV_RING + ((size_t)1 << 20);
+    if (device_bytes) *device_bytes = dev;
+    if (pinned_bytes) *pinned_bytes = pin;
+    return FFL_OK;
+}
+
 int ffl_num_levels(const ffl_ctx *c) { return c ? c->levels : -1; }
 
 int ffl_level_size(const ffl_ctx *c, int level, int *out_wh) {
@@ -628,10 +681,18 @@ int ffl_host_alloc(ffl_ctx *c, size_t bytes, void **out) {
 
 int ffl_host_free(ffl_ctx *c, void *ptr) {
     if (!c) return FFL_ERR_INVALID;
+    std::unique_lock<std::mutex> ul(c->up_mu);  // no upload out of the buffer starts while it is being freed
     CtxLock lk(c->mu);
+    bool mine = false;
+    for (auto &hb : c->host_bufs) mine |= hb.first == ptr;
+    if (!mine) return set_err(c, FFL_ERR_INVALID, "ffl_host_free: not a buffer of this context");
+    HIPCHK(c, hipSetDevice(c->device));
+    lk.unlock();
+    hipError_t e = hipStreamSynchronize(c->s_copy);  // no transfer may still be reading it (waited for without the lock)
+    lk.lock();
+    HIPCHK(c, e);
     for (size_t i = 0; i < c->host_bufs.size(); i++)
         if (c->host_bufs[i].first == ptr) {
-            HIPCHK(c, hipStreamSynchronize(c->s_copy));  // no transfer may still be reading it
             HIPCHK(c, hipHostFree(ptr));
             c->host_bufs.erase(c->host_bufs.begin() + i);
             return FFL_OK;
@@ -645,6 +706,7 @@ int ffl_host_free(ffl_ctx *c, void *ptr) {
 int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames, int width, int height, int channels,
                       ptrdiff_t stride_bytes) {
     if (!c) return FFL_ERR_INVALID;
+    std::unique_lock<std::mutex> ul(c->up_mu);
     CtxLock lk(c->mu);
     if (!frames || n < 1 || first < 0 || first + n > c->n_fslots)
         return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames: bad frame slot range %d..%d", first, first + n - 1);
@@ -698,9 +760,15 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
         size_t pending = 0;
         for (int i = 0; i < n; i++) {
             const int fs = first + i;
-            // the previous transfer out of this slot's staging area must have left the host buffer
-            if (c->ev_uploaded[fs]) HIPCHK(c, hipEventSynchronize(c->ev_uploaded[fs]));
-            c->pool.copy(stage0 + (size_t)i * fbytes, (ptrdiff_t)row, frames[i], stride_bytes, row, height, g_copy_threads);
+            // the previous transfer out of this slot's staging area must have left the host buffer; the wait and the
+            // staging copy run WITHOUT the context lock (up_mu keeps other uploaders out of the staging areas and the pool)
+            hipEvent_t prev = c->ev_uploaded[fs];
+            lk.unlock();
+            hipError_t pe = prev ? hipEventSynchronize(prev) : hipSuccess;
+            if (pe == hipSuccess)
+                c->pool.copy(stage0 + (size_t)i * fbytes, (ptrdiff_t)row, frames[i], stride_bytes, row, height, g_copy_threads);
+            lk.lock();
+            HIPCHK(c, pe);
             pending += fbytes;
             if (pending >= ((size_t)8 << 20) || i == n - 1) {
                 int rc = send(sent, i + 1);
@@ -725,6 +793,7 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
 int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *frames, int sw, int sh,
                           ptrdiff_t stride_bytes, int rgb_order, int rw, int rh, int crop_x, int crop_y) {
     if (!c) return FFL_ERR_INVALID;
+    std::unique_lock<std::mutex> ul(c->up_mu);
     CtxLock lk(c->mu);
     if (!frames || n < 1 || first < 0 || first + n > c->n_fslots)
         return set_err(c, FFL_ERR_INVALID, "ffl_upload_frames_raw: bad frame slot range %d..%d", first, first + n - 1);
@@ -752,7 +821,12 @@ int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *fr
     for (int i = 0; i < n; i++) {
         const int fs = first + i;
         auto &rb = c->raw[c->raw_next++ % FFL_RAW_RING];
-        if (rb.busy) HIPCHK(c, hipEventSynchronize(rb.ev));  // its previous frame has left both buffers
+        if (rb.busy) {  // its previous frame has left both buffers (waited for without the context lock)
+            lk.unlock();
+            hipError_t be = hipEventSynchronize(rb.ev);
+            lk.lock();
+            HIPCHK(c, be);
+        }
         if (rb.cap < fbytes) {
             hipFree(rb.d);
             hipHostFree(rb.h);
@@ -766,9 +840,10 @@ int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *fr
         const uint8_t *data = frames[i];
         // a tightly packed frame in ffl_host_alloc memory goes to the device straight out of it
         const bool direct = (size_t)stride_bytes == fp.stride && in_host_buf(c, data, fbytes);
-        if (direct) {
-        } else {
+        if (!direct) {
+            lk.unlock();  // the staging copy runs without the context lock (up_mu protects the ring and the pool)
             c->pool.copy(rb.h, (ptrdiff_t)fp.stride, data, stride_bytes, fp.stride, sh, g_copy_threads);
+            lk.lock();
         }
         for (size_t l = 0; l < c->lanes.size(); l++) {  // batches still reading the slot's previous frame
             hipEvent_t e = c->ev_last_use[(size_t)fs * c->lanes.size() + l];
@@ -1011,25 +1086,40 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         ffl_ctx::Lane::GraphEntry *ge = nullptr;
         for (auto &g : L.graphs)
             if (g.n == n && g.nU == nU && g.pov == pov_mode && g.epoch == g_opt_epoch) ge = &g;
-        if (!ge) {
+        if (!ge && c->graph_bad_epoch != g_opt_epoch) {
             ffl_ctx::Lane::GraphEntry g = {n, nU, pov_mode, g_opt_epoch, nullptr, nullptr};
-            HIPCHK(c, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-            int rc = enqueue_batch(c, L, T, n, nU, pov_mode, nullptr);
-            hipError_t ce = hipStreamEndCapture(st, &g.graph);
-            if (rc) return rc;
-            HIPCHK(c, ce);
-            HIPCHK(c, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
-            if (L.graphs.size() >= 16) {  // bounded cache: callers that vary the batch shape a lot re-capture
-                // a replay may still be queued: graph resources are released once the lane's stream has drained
-                HIPCHK(c, hipStreamSynchronize(st));
-                hipGraphExecDestroy(L.graphs.front().exec);
-                hipGraphDestroy(L.graphs.front().graph);
-                L.graphs.erase(L.graphs.begin());
+            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                const int rc = enqueue_batch(c, L, T, n, nU, pov_mode, nullptr);
+                const hipError_t ce = hipStreamEndCapture(st, &g.graph);  // always: the stream must leave capture mode
+                ok = rc == FFL_OK && ce == hipSuccess && g.graph &&
+                     hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) == hipSuccess;
             }
-            L.graphs.push_back(g);
-            ge = &L.graphs.back();
+            if (ok) {
+                if (L.graphs.size() >= 16) {  // bounded cache: callers that vary the batch shape a lot re-capture
+                    // a replay may still be queued: graph resources are released once the lane's stream has drained
+                    HIPCHK(c, hipStreamSynchronize(st));
+                    hipGraphExecDestroy(L.graphs.front().exec);
+                    hipGraphDestroy(L.graphs.front().graph);
+                    L.graphs.erase(L.graphs.begin());
+                }
+                L.graphs.push_back(g);
+                ge = &L.graphs.back();
+            } else {
+                // nothing of the failed capture is kept (it would leak once per batch), the sticky error is cleared, and
+                // this context launches eagerly until the option set changes -- the batch itself is not lost
+                if (g.exec) hipGraphExecDestroy(g.exec);
+                if (g.graph) hipGraphDestroy(g.graph);
+                (void)hipGetLastError();
+                c->graph_bad_epoch = g_opt_epoch;
+            }
         }
-        HIPCHK(c, hipGraphLaunch(ge->exec, st));
+        if (ge) {
+            HIPCHK(c, hipGraphLaunch(ge->exec, st));
+        } else {
+            int rc = enqueue_batch(c, L, T, n, nU, pov_mode, nullptr);
+            if (rc) return rc;
+        }
     } else {
         int rc = enqueue_batch(c, L, T, n, nU, pov_mode, cap);
         if (rc) return rc;
@@ -1135,6 +1225,7 @@ int ffl_pass1_results(ffl_ctx *c, int n, const int *slots, float cut_threshold, 
 int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const double *cy, const int *is_cut, int pov_mode,
                double *out) {
     if (!c) return FFL_ERR_INVALID;
+    std::unique_lock<std::mutex> pl(c->post_mu);  // one pass-2 call at a time owns stream `post`, h_rtab and h_radial
     CtxLock lk(c->mu);
     if (n < 1 || n > FFL_MAXB || !slots || !cx || !cy || !out) return set_err(c, FFL_ERR_INVALID, "ffl_radial: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
@@ -1161,7 +1252,10 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
         ProfScope ps(c, FFL_K_RADIAL, st);
         ffl_launch_radial(c->d_rtab, m, c->w, c->h, pov_mode, c->d_wytab, c->d_rpsum, c->d_radial, st);
     }
-    HIPCHK(c, hipStreamSynchronize(st));  // k_radial_final stored into the mapped pinned buffer
+    lk.unlock();  // the wait (for the batches the slots come from, then pass 2) does not hold up uploads / submissions
+    hipError_t se = hipStreamSynchronize(st);  // k_radial_final stored into the mapped pinned buffer
+    lk.lock();
+    HIPCHK(c, se);
     HIPCHK(c, hipGetLastError());
     for (int j = 0; j < m; j++) out[map[j]] = c->h_radial[j];
     return FFL_OK;
@@ -1186,12 +1280,19 @@ int ffl_download_flow(ffl_ctx *c, int slot, float *dst) {
 
 int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
     if (!c) return FFL_ERR_INVALID;
+    std::unique_lock<std::mutex> pl(c->post_mu);
     CtxLock lk(c->mu);
     if (slot < 0 || slot >= c->n_slots || !src) return set_err(c, FFL_ERR_INVALID, "ffl_upload_flow: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->s_post;
-    if (c->slot_state[slot]) HIPCHK(c, hipEventSynchronize(c->ev_slot_done[slot]));
-    HIPCHK(c, hipStreamSynchronize(st));
+    {
+        hipEvent_t ev = c->slot_state[slot] ? c->ev_slot_done[slot] : nullptr;
+        lk.unlock();
+        hipError_t e = ev ? hipEventSynchronize(ev) : hipSuccess;
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        lk.lock();
+        HIPCHK(c, e);
+    }
     HIPCHK(c, hipMemcpy(c->d_flow + (size_t)slot * 2 * c->N, src, sizeof(float) * 2 * c->N, hipMemcpyHostToDevice));
     c->h_ptab->pt.flow[0][0] = c->d_flow + (size_t)slot * 2 * c->N;  // the stream was drained above: the pinned copy is free
     c->h_ptab->pt.res[0] = c->d_res + slot;
@@ -1211,9 +1312,12 @@ int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
 int ffl_submit_pair(ffl_ctx *c, int slot, const uint8_t *prev, const uint8_t *next, int width, int height, int channels,
                     ptrdiff_t stride_bytes, int pov_mode) {
     if (!c) return FFL_ERR_INVALID;
-    CtxLock lk(c->mu);
-    if (slot < 0 || 2 * slot + 1 >= c->n_fslots || slot >= c->n_slots)
+    // no lock around the three calls (each takes its own; holding `mu` here would invert the up_mu -> mu order): calls on
+    // distinct slots from several threads interleave safely, n_fslots / n_slots are fixed at creation
+    if (slot < 0 || 2 * slot + 1 >= c->n_fslots || slot >= c->n_slots) {
+        CtxLock lk(c->mu);
         return set_err(c, FFL_ERR_INVALID, "ffl_submit_pair: slot %d needs frame slots %d,%d and a flow slot", slot, 2 * slot, 2 * slot + 1);
+    }
     int rc = ffl_upload_frame(c, 2 * slot, prev, width, height, channels, stride_bytes);
     if (rc) return rc;
     rc = ffl_upload_frame(c, 2 * slot + 1, next, width, height, channels, stride_bytes);
@@ -1226,15 +1330,20 @@ int ffl_sync(ffl_ctx *c) {
     if (!c) return FFL_ERR_INVALID;
     CtxLock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    HIPCHK(c, hipStreamSynchronize(c->s_copy));
-    for (auto &L : c->lanes) HIPCHK(c, hipStreamSynchronize(L.st));
-    HIPCHK(c, hipStreamSynchronize(c->s_post));
+    std::vector<hipStream_t> sts;  // the streams live as long as the context: wait for them without the lock
+    sts.push_back(c->s_copy);
+    for (auto &L : c->lanes) sts.push_back(L.st);
+    sts.push_back(c->s_post);
+    lk.unlock();
+    hipError_t e = hipSuccess;
+    for (auto s : sts)
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    lk.lock();
+    HIPCHK(c, e);
     return FFL_OK;
 }
 
-int ffl_set_option(const char *name, int value) {
-    if (!name) return FFL_ERR_INVALID;
-    g_opt_epoch++;
+static int set_option_impl(const char *name, int value) {
     if (!strcmp(name, "blur_tile_h")) {  // fixed: the box-sum order is anchored to blocks of 16 rows
         return value == 16 ? FFL_OK : FFL_ERR_INVALID;
     }
@@ -1283,6 +1392,13 @@ int ffl_set_option(const char *name, int value) {
     return FFL_ERR_INVALID;
 }
 
+int ffl_set_option(const char *name, int value) {
+    if (!name) return FFL_ERR_INVALID;
+    const int rc = set_option_impl(name, value);
+    if (rc == FFL_OK) g_opt_epoch++;  // only an option that was actually applied invalidates the captured graphs
+    return rc;
+}
+
 int ffl_profile_enable(ffl_ctx *c, unsigned class_mask) {
     if (!c) return FFL_ERR_INVALID;
     CtxLock lk(c->mu);
@@ -1294,6 +1410,7 @@ int ffl_profile_enable(ffl_ctx *c, unsigned class_mask) {
 
 int ffl_profile_read(ffl_ctx *c, int k, int *launches, double *total_ms) {
     if (!c || k < 0 || k >= FFL_K_COUNT) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
     int rc = ffl_sync(c);
     if (rc) return rc;
     prof_collect(c);

@@ -8,27 +8,49 @@ sine path ("sine-translate"), optionally with a breathing zoom about the image c
 import numpy as np
 
 
-def sine_translate_frames(n_frames, width, height, seed=0, amp=(4.0, 4.0), period=16, zoom=0.0, t0=0):
-    """Return (n_frames, height, width) uint8 gray frames."""
+def sine_translate_frames(n_frames, width, height, seed=0, amp=(4.0, 4.0), period=16, zoom=0.0, t0=0, workers=None):
+    """Return (n_frames, height, width) uint8 gray frames.  Frames are independent of each other, so large clips are
+    synthesised by a few threads (numpy releases the GIL); the result does not depend on `workers`."""
     rng = np.random.default_rng(seed)
     a = rng.uniform(5.0, 25.0, 12)
     fx = rng.uniform(0.02, 0.25, 12)
     fy = rng.uniform(0.02, 0.25, 12)
     ph = rng.uniform(0.0, 2.0 * np.pi, 12)
-    y, x = np.mgrid[0:height, 0:width].astype(np.float64)
     cx, cy = (width - 1) / 2.0, (height - 1) / 2.0
     out = np.empty((n_frames, height, width), np.uint8)
-    for i in range(n_frames):
+    ROWS = max(32, 131072 // width)   # rows per block: the float64 temporaries of a block stay in cache (same elementwise arithmetic, same bits)
+
+    def one(i):
         t = t0 + i
         dx = amp[0] * np.sin(2.0 * np.pi * t / period)
         dy = amp[1] * np.sin(2.0 * np.pi * t / period + np.pi / 3.0)
         s = 1.0 + zoom * np.sin(2.0 * np.pi * t / period)
-        xs = (x - cx) / s + cx - dx
-        ys = (y - cy) / s + cy - dy
-        f = np.full((height, width), 128.0)
-        for k in range(12):
-            f += a[k] * np.sin(fx[k] * xs + fy[k] * ys + ph[k])
-        out[i] = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+        xrow = (np.arange(width, dtype=np.float64) - cx) / s + cx - dx            # xs[y, x] depends on x only
+        for r0 in range(0, height, ROWS):
+            r1 = min(r0 + ROWS, height)
+            ycol = ((np.arange(r0, r1, dtype=np.float64) - cy) / s + cy - dy)[:, None]   # ys[y, x] depends on y only
+            f = np.full((r1 - r0, width), 128.0)
+            arg = np.empty((r1 - r0, width))
+            for k in range(12):
+                np.add(fx[k] * xrow, fy[k] * ycol, out=arg)                      # fx*xs + fy*ys (each product rounded as before)
+                arg += ph[k]
+                np.sin(arg, out=arg)
+                arg *= a[k]
+                f += arg
+            np.rint(f, out=f)
+            np.clip(f, 0, 255, out=f)
+            out[i, r0:r1] = f.astype(np.uint8)
+
+    if workers is None:
+        import os
+        workers = min(8, os.cpu_count() or 1) if (width * height >= (1 << 19) and n_frames > 1) else 1
+    if workers > 1 and n_frames > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(workers) as ex:
+            list(ex.map(one, range(n_frames)))
+    else:
+        for i in range(n_frames):
+            one(i)
     return out
 
 

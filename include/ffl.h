@@ -27,9 +27,10 @@
  *
  * Threading: a context is bound to one device and is internally stream-ordered.  Every entry point locks the
  * context, so calls may come from several host threads (an uploader, a submitter and a result collector working
- * on distinct slots); the calls that wait for the device (ffl_pass1_result(s), ffl_download_flow)
- * release the lock while they wait.  ffl_last_error() returns the message of the context's most recent failing
- * call by any thread.  ffl_set_option() is process-wide and not synchronised: set options before creating
+ * on distinct slots).  No call holds the context lock while it waits for the device or copies frames into
+ * staging (ffl_pass1_result(s), ffl_download_flow, ffl_radial, ffl_upload_flow, ffl_sync, ffl_host_free,
+ * ffl_upload_frames(_raw) all release it for that time); uploads are serialised among themselves, pass-2 calls among
+ * themselves.  ffl_last_error() returns the message of the context's most recent failing call by any thread.  ffl_set_option() is process-wide and not synchronised: set options before creating
  * contexts.  Sizes: 16x16 <= width x height, 20 * width * height < 2^32 (32-bit plane offsets in the kernels).
  */
 #ifndef FFL_H
@@ -64,8 +65,17 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
                ffl_ctx **out);
 void ffl_destroy(ffl_ctx *ctx);
 
-/* Last error text for ctx (or for the failed ffl_create when ctx == NULL). Never NULL. */
+/* Last error text for ctx (or for the calling thread's failed ffl_create when ctx == NULL). Never NULL.  The text is a
+ * per-thread copy taken under the context lock: valid until the calling thread's next ffl_last_error(). */
 const char *ffl_last_error(const ffl_ctx *ctx);
+
+/* Sizing a context before creating it (no counterpart in the reference, whose `precomputed` list simply grows in host
+ * memory, FF:1191): free / total device memory of `device`, and the device + page-locked host bytes ffl_create would
+ * allocate for these arguments under the current "lanes" option.  backend.precompute_all uses them to pick a batch size
+ * that fits, or to refuse a chunk that cannot stay resident with a message instead of a failed hipMalloc. */
+int ffl_device_mem_info(int device, size_t *free_bytes, size_t *total_bytes);
+int ffl_estimate_bytes(int width, int height, int n_frame_slots, int n_flow_slots, int max_batch, size_t *device_bytes,
+                       size_t *pinned_bytes);
 
 /* Copy one frame into frame slot `fslot`.  `channels` is 1 (gray uint8, what the reference feeds
  * Farneback, FF:1082) or 3 (BGR uint8 as cv2.VideoCapture.read returns, FF:178; converted on the

@@ -99,5 +99,6 @@ if __name__ == "__main__":
         for seed in (1, 10, 11, 12, 13, 14, 15, 16, 17):     # N = 1 and the clips of ranks 0..7 of bench.py --gpus N
             generate(1920, 1080, 32, seed)
         generate(3840, 2160, 32, 1)
+        generate(2880, 2880, 32, 2)                           # one eye of configs[4] (bench.py's large_image extra)
         generate(256, 256, 64, 1)
         generate(256, 256, 256, 1)

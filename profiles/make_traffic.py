@@ -6,6 +6,8 @@ PMC passes of the bench command:
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d W -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline
     python profiles/make_traffic.py F/*/*counter_collection.csv W/*/*counter_collection.csv k_blur_solve 1920x1080 32 [tag]
 
+profiles/traffic.json holds one entry per workload ("1920x1080_b32", "3840x2160_b32", "256x256_b256", ...).
+
 The file records the signature of the device sources it was measured on (bench.kernel_signature()); bench.py
 reports `roofline.traffic` only while that signature matches the sources it runs.
 
@@ -38,14 +40,23 @@ def main():
     f, nf = per_launch(fcsv, kernel, "FETCH_SIZE")
     w, nw = per_launch(wcsv, kernel, "WRITE_SIZE")
     assert nf == nw and nf > 0, (nf, nw)
-    out = {"workload": workload, "batch": int(batch), "kernel": kernel, "launches": nf,
-           "fetch_size_kib_per_launch_raw": f / nf, "write_size_kib_per_launch": w / nw,
-           "hbm_bytes_per_launch": (2.0 * f / nf + w / nw) * 1024.0,
-           "kernel_signature": bench.kernel_signature(), "fuse_first": bench.FUSE_FIRST, "captured": tag,
-           "correction": "FETCH_SIZE x2 on gfx950 (calibrated, profiles/tools/calib_fetch.hip), WRITE_SIZE exact, KiB units"}
+    entry = {"workload": workload, "batch": int(batch), "kernel": kernel, "launches": nf,
+             "fetch_size_kib_per_launch_raw": f / nf, "write_size_kib_per_launch": w / nw,
+             "hbm_bytes_per_launch": (2.0 * f / nf + w / nw) * 1024.0,
+             "kernel_signature": bench.kernel_signature(), "fuse_first": bench.FUSE_FIRST, "captured": tag}
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "traffic.json")
-    json.dump(out, open(path, "w"), indent=1)
-    print(json.dumps(out))
+    doc = {"workloads": {}}
+    if os.path.exists(path):
+        try:
+            old = json.load(open(path))
+            if "workloads" in old:
+                doc = old
+        except ValueError:
+            pass
+    doc["correction"] = "FETCH_SIZE x2 on gfx950 (calibrated, profiles/tools/calib_fetch.hip), WRITE_SIZE exact, KiB units"
+    doc["workloads"][f"{workload}_b{int(batch)}"] = entry      # one entry per workload: bench.load_traffic() looks it up
+    json.dump(doc, open(path, "w"), indent=1)
+    print(json.dumps(entry))
 
 
 if __name__ == "__main__":

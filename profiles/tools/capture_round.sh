@@ -13,6 +13,17 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_W -o w -- python3 be
 cp profiles/traffic.json /tmp/traffic_prev.json
 BATCH=$(python -c "import json; print(json.load(open('$O/${TAG}_bench_under_rocprof.json'))['config']['pairs_per_step'])")
 python profiles/make_traffic.py $O/${TAG}_F/f_counter_collection.csv $O/${TAG}_W/w_counter_collection.csv k_blur_solve 1920x1080 $BATCH $TAG
+# the other workloads of the bench line: configs[2] / the configs[4] eye (B = 32, one lane) and the reference's 256x256
+# operating point (B = 256): FETCH / WRITE passes -> their own traffic.json entries (bench.py: large_image / small_image)
+for WL in "3840 2160 32" "2880 2880 32" "256 256 256"; do
+  set -- $WL
+  N=${1}x${2}
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_F_$N -o f -- python3 bench.py --width $1 --height $2 --batch $3 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_W_$N -o w -- python3 bench.py --width $1 --height $2 --batch $3 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  python profiles/make_traffic.py $O/${TAG}_F_$N/f_counter_collection.csv $O/${TAG}_W_$N/w_counter_collection.csv k_blur_solve $N $3 $TAG
+  (python profiles/summarize_pmc.py $O/${TAG}_F_$N/f_counter_collection.csv k_; python profiles/summarize_pmc.py $O/${TAG}_W_$N/w_counter_collection.csv k_) > $O/${TAG}_pmc_fetch_write_$N.txt
+  echo "traffic $N done"
+done
 cp profiles/traffic.json $O/${TAG}_traffic.json
 # the bench line last, so that it already carries this capture's traffic (profiles/traffic.json, same kernel signature)
 python bench.py > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err

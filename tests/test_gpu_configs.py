@@ -38,6 +38,14 @@ def _run_bench_batch(ctx, frames, B):
     return recs, dots
 
 
+def _require_golden_match(status, detail):
+    """check_batch returns None when this machine's numpy / libm rounds the synthetic texture differently from the
+    build container's (the golden then describes other inputs): that is a SKIP of the golden half, never a silent pass."""
+    if status is None:
+        pytest.skip(f"golden comparison not possible here: {detail}")
+    assert status is True, detail
+
+
 def _check_reductions_on_own_flow(ctx, j, rec, flow):
     ox, oy, ov = orc.max_divergence_np(flow)
     assert (rec[0], rec[1]) == (ox, oy) and np.float32(rec[2]).tobytes() == np.float32(ov).tobytes(), j
@@ -62,7 +70,7 @@ def test_shipped_configuration_1080p_b32_against_oracle(lanes):
     finally:
         _capi.set_option("lanes", 2)
     status, detail = golden_check.check_batch(gold, frames, recs, dots, lambda j: flows[j])
-    assert status is not False, detail
+    _require_golden_match(status, detail)
     for j in (0, B // 2 - 1, B - 1):                                   # first, middle, last pair of the batch
         assert np.array_equal(flows[j], orc.farneback(frames[j], frames[j + 1])), j
     for j in range(B):
@@ -81,7 +89,7 @@ def test_4k_b32_against_oracle():
         with _capi.Context(W, H, frame_slots=B + 2, flow_slots=B, max_batch=B) as ctx:
             recs, dots = _run_bench_batch(ctx, frames, B)
             status, detail = golden_check.check_batch(gold, frames, recs, dots, ctx.download_flow)
-            assert status is not False, detail
+            _require_golden_match(status, detail)
             f5 = ctx.download_flow(5)
             assert np.array_equal(f5, orc.farneback(frames[5], frames[6]))      # one pair against the oracle here
             for j in range(0, B - 16, 3):
@@ -91,6 +99,33 @@ def test_4k_b32_against_oracle():
                 assert tuple(recs[j]) == tuple(recs[j + 16])
     finally:
         _capi.set_option("lanes", 2)
+
+
+def test_every_rank_clip_of_the_scaling_bench_against_goldens():
+    """bench.py --gpus N gives rank r the clip of seed 10 + r (weak scaling, configs[3]).  The driver's 8-GPU node is the
+    only place ranks 2..7 ever run, so their goldens (tests/golden/bench_1920x1080_b32_s10..17.json) are compared here on
+    the one GPU of the test box: the exact bench step per clip, 32 records + 32 scalars + 3 flow crc32 each."""
+    from concurrent.futures import ThreadPoolExecutor
+    W, H, B = 1920, 1080, 32
+    seeds = list(range(10, 18))
+    with ThreadPoolExecutor(8) as ex:
+        clips = list(ex.map(lambda sd: sine_translate_frames(B + 1, W, H, seed=sd), seeds))
+    compared = 0
+    try:
+        _capi.set_option("lanes", 1)
+        with _capi.Context(W, H, frame_slots=B + 2, flow_slots=B, max_batch=B) as ctx:
+            for sd, frames in zip(seeds, clips):
+                gold = golden_check.load_golden(W, H, B, sd)
+                assert gold is not None, sd
+                recs, dots = _run_bench_batch(ctx, frames, B)
+                status, detail = golden_check.check_batch(gold, frames, recs, dots, ctx.download_flow)
+                assert status is not False, (sd, detail)
+                compared += status is True
+    finally:
+        _capi.set_option("lanes", 2)
+    if compared == 0:
+        pytest.skip("no clip's synthetic frames match the goldens on this machine (numpy/libm rounding)")
+    assert compared == len(seeds)
 
 
 def test_config4_stereo_5760x2880_split_per_eye():
@@ -238,7 +273,7 @@ def test_reference_operating_point_256x256_b256_against_goldens():
             for s0 in range(0, B, 64):
                 dots += ctx.radial(slots[s0:s0 + 64], centers[s0:s0 + 64], [r[4] for r in recs[s0:s0 + 64]], False)
             status, detail = golden_check.check_batch(gold, frames, recs, dots, lambda j: ctx.download_flow(slots[j]))
-            assert status is not False, (step, detail)
+            _require_golden_match(status, f"step {step}: {detail}")
         dots256 = ctx.radial(slots, centers, [r[4] for r in recs], False)     # pass 2 for 256 pairs in one call
         assert dots256 == dots
 
@@ -366,3 +401,68 @@ def test_non_default_options_change_no_bit():
         assert [tuple(r) for r in got[0]] == [tuple(r) for r in ref[0]], opts
         assert got[1] == ref[1], opts
         assert np.array_equal(got[2], ref[2]), opts
+
+
+def test_largest_batch_1080p_b256_two_lanes_equals_b32_batches():
+    """The largest context the API allows at the headline size: 1080p, FFL_MAX_BATCH = 256 pairs per batch, 257 unique
+    frames, two lanes (~ 150 GB of work buffers: the R planes of 512 frames alone are 28 GB, far beyond 32-bit byte
+    offsets).  Its 256 records must equal those of the same pairs run as eight 32-pair batches (the configuration the
+    goldens pin), three flow fields bit for bit, one of them against the oracle."""
+    W, H, B = 1920, 1080, _capi.FFL_MAX_BATCH
+    base = sine_translate_frames(33, W, H, seed=1)
+    frames = [base[i % 33] for i in range(B + 1)]
+    need, pinned = _capi.estimate_bytes(W, H, B + 2, B, B)
+    free, total = _capi.device_mem_info(0)
+    assert need > 100e9, need                      # this IS the big one
+    if need > 0.9 * free:
+        pytest.skip(f"needs {need / 1e9:.0f} GB of device memory, {free / 1e9:.0f} GB free")
+    try:
+        _capi.set_option("lanes", 2)
+        with _capi.Context(W, H, frame_slots=B + 2, flow_slots=B, max_batch=B) as ctx:
+            ctx.upload_frames(0, frames)
+            slots = list(range(B))
+            ctx.flow_pairs(list(range(B)), list(range(1, B + 1)), slots)
+            big = ctx.pass1_results(slots, 7.0)
+            keep = {j: ctx.download_flow(j) for j in (0, 131, 255)}
+            free_with_ctx, _ = _capi.device_mem_info(0)
+        assert free - free_with_ctx <= need * 1.02 and free - free_with_ctx >= need * 0.9, (free - free_with_ctx, need)
+        with _capi.Context(W, H, frame_slots=34, flow_slots=64, max_batch=32) as ctx:
+            ctx.upload_frames(0, list(base))
+            for s0 in range(0, B, 32):
+                f0 = [(s0 + i) % 33 for i in range(32)]
+                f1 = [(s0 + i + 1) % 33 for i in range(32)]
+                sl = [(s0 // 32 % 2) * 32 + i for i in range(32)]
+                ctx.flow_pairs(f0, f1, sl)
+                small = ctx.pass1_results(sl, 7.0)
+                assert [tuple(r) for r in small] == [tuple(r) for r in big[s0:s0 + 32]], s0
+                for j, f in keep.items():
+                    if s0 <= j < s0 + 32:
+                        assert np.array_equal(ctx.download_flow(sl[j - s0]), f), j
+    finally:
+        _capi.set_option("lanes", 2)
+    assert np.array_equal(keep[131], orc.farneback(frames[131], frames[132]))
+
+
+def test_create_that_exceeds_device_memory_fails_cleanly_and_leaves_the_device_usable():
+    """A context that cannot fit (4K, thousands of resident flow fields) must come back as FFL_ERR_HIP with the failing
+    allocation named, free everything it had already allocated, and leave the device usable: the next ffl_create
+    succeeds and computes the right flow."""
+    W, H = 3840, 2160
+    free0, total = _capi.device_mem_info(0)
+    slots = int(total * 1.2 // (8 * W * H))                # flow fields worth 120 % of the whole device
+    need, _ = _capi.estimate_bytes(W, H, 4, slots, 1)
+    assert need > total
+    with pytest.raises(_capi.FFLError, match=r"ffl_create failed \(2\).*hipMalloc"):
+        _capi.Context(W, H, frame_slots=4, flow_slots=slots, max_batch=1)
+    free1, _ = _capi.device_mem_info(0)
+    assert free1 >= free0 - (64 << 20), (free0, free1)      # nothing of the failed context is left behind
+    fr = sine_translate_frames(2, 320, 180, seed=1)
+    with _capi.Context(320, 180, max_batch=1) as ctx:
+        ctx.submit_pair(0, fr[0], fr[1])
+        assert np.array_equal(ctx.download_flow(0), orc.farneback(fr[0], fr[1]))
+    # the reference-shaped chunk API sizes itself against free memory and says what to do instead of failing in hipMalloc
+    from funscript_flow_amd import backend
+    with pytest.raises(_capi.FFLError, match="lower batch_size"):
+        backend._fit_chunk(W, H, slots, 0, 32)
+    B, bytes_needed = backend._fit_chunk(1920, 1080, 3000, 0, 32)      # the reference's default chunk (FF:2647) at 1080p
+    assert 1 <= B <= 32 and bytes_needed < free1

@@ -126,7 +126,7 @@ class OracleEngine:  # the checker standing in for a device: exercises the shard
 
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
-frames = sine_translate_frames(12, 96, 64, seed=5, amp=(2.0, 1.5), period=9)
+frames = sine_translate_frames({nframes}, 96, 64, seed=5, amp=(2.0, 1.5), period=9)
 def allgather(obj):
     out = [None] * world
     dist.all_gather_object(out, obj)
@@ -142,27 +142,39 @@ dist.destroy_process_group()
 """
 
 
-def test_sharded_two_pass_gloo_world2(tmp_path):
-    """N>1 path on CPU: 2 ranks, contiguous pair blocks and round-robin (blocks of 1 and 2 pairs: BASELINE's
-    "frame-pairs sharded round-robin"), host all-gather of pass-1 records only."""
-    out = str(tmp_path / "dots.npy")
-    script = tmp_path / "worker.py"
-    script.write_text(_WORKER.format(root=ROOT, out=out))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                           "--master-addr", "127.0.0.1", "--master-port", "29571", str(script)], env=env, timeout=300)
+def _run_sharded(tmp_path, world, nframes, port):
+    out = str(tmp_path / f"dots_{world}_{nframes}.npy")
+    script = tmp_path / f"worker_{world}_{nframes}.py"
+    script.write_text(_WORKER.format(root=ROOT, out=out, nframes=nframes))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)], env=env, timeout=600)
     got = np.load(out)
     # single-process reference of the same chunk
     from funscript_flow_amd.synth import sine_translate_frames
-    frames = sine_translate_frames(12, 96, 64, seed=5, amp=(2.0, 1.5), period=9)
-    flows = [orc.farneback(frames[j], frames[j + 1]) for j in range(11)]
+    frames = sine_translate_frames(nframes, 96, 64, seed=5, amp=(2.0, 1.5), period=9)
+    flows = [orc.farneback(frames[j], frames[j + 1]) for j in range(nframes - 1)]
     pos = [orc.max_divergence_np(f)[:2] for f in flows]
     cuts = [bool(orc.mean_mag_np(f) > 7) for f in flows]
     centers = orc.smooth_centers(pos)
     want = np.array([orc.radial_np(f, c, k) for f, c, k in zip(flows, centers, cuts)])
-    assert got.shape == (3, 11)
+    assert got.shape == (3, nframes - 1)
     for g in got:
         assert np.array_equal(g, want)
+
+
+def test_sharded_two_pass_gloo_world2(tmp_path):
+    """N>1 path on CPU: 2 ranks, contiguous pair blocks and round-robin (blocks of 1 and 2 pairs: BASELINE's
+    "frame-pairs sharded round-robin"), host all-gather of pass-1 records only."""
+    _run_sharded(tmp_path, 2, 12, 29571)
+
+
+def test_sharded_two_pass_gloo_world8_with_empty_and_one_pair_shards(tmp_path):
+    """8 ranks (north_star's widest configuration) on FEWER pairs than 2 x ranks: 5 pairs leave three ranks with an empty
+    shard under every assignment (they must still take part in both gathers), 11 pairs give shards of one and two pairs;
+    the +-6 smoothing window then spans every shard.  Results must equal the single-process chunk exactly."""
+    _run_sharded(tmp_path, 8, 6, 29573)
+    _run_sharded(tmp_path, 8, 12, 29575)
 
 
 def test_shard_pairs_partitions_under_both_assignments():
