@@ -533,6 +533,7 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
         if (e_ != hipSuccess) {                                                                          \
             int rc_ = set_err(nullptr, FFL_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_));      \
             ffl_destroy(c);                                                                              \
+            (void)hipGetLastError(); /* the failure is reported HERE: do not leave it to poison a later call's check */ \
             return rc_;                                                                                  \
         }                                                                                                \
     } while (0)
