@@ -290,7 +290,8 @@ def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None, pinned=False
     base = base[:17]                                  # one period of the clip, cycled
     if bgr:
         base = gray_to_bgr(base)
-    with _capi.Context(W, H, device=device, max_batch=B, frame_slots=2 * B + 2, flow_slots=pipeline.min_flow_slots(B)) as ctx:
+    with _capi.Context(W, H, device=device, max_batch=B, frame_slots=pipeline.min_frame_slots(B, 2),
+                       flow_slots=pipeline.min_flow_slots(B, 2)) as ctx:      # room for two batches queued ahead
         if pinned:
             store = ctx.pinned_frames(n_frames, 3 if bgr else 1)
             for i in range(n_frames):

@@ -32,9 +32,15 @@ def smooth_centers(pos_centers, radius=SMOOTH_RADIUS):
     return out
 
 
-def min_flow_slots(max_batch):
-    """Flow slots a streaming two-pass schedule needs (the bound include/ffl.h documents for ffl_create)."""
-    return 2 * max_batch + 2 * SMOOTH_RADIUS + 1
+def min_flow_slots(max_batch, depth=1):
+    """Flow slots a streaming two-pass schedule needs with `depth` + 1 batches in flight (depth = 1: the bound
+    include/ffl.h documents for ffl_create)."""
+    return (depth + 1) * max_batch + 2 * SMOOTH_RADIUS + 1
+
+
+def min_frame_slots(max_batch, depth=1):
+    """Frame slots for `depth` batches in flight + the one being staged, B + 1 frames each."""
+    return (depth + 1) * (max_batch + 1)
 
 
 def shard_range(n_items, world, rank):
@@ -71,12 +77,22 @@ class PairEngine:
     of pairs <= j+6 are known (or the chunk has ended), after which its flow slot is recycled.
     """
 
-    def __init__(self, ctx, upload=None):
+    def __init__(self, ctx, upload=None, depth=None):
         """`upload(first_slot, frames)` puts a run of frames into consecutive frame slots; the default takes
-        gray (or same-size BGR) operands, frontend.DecodedUploader takes frames as decoded (any size)."""
+        gray (or same-size BGR) operands, frontend.DecodedUploader takes frames as decoded (any size).
+        `depth`: batches queued on the device before the oldest one's results are collected (default: 2 when the
+        context has the slots for it -- 3B + 3 frame slots, 3B + 13 flow slots -- else 1).  With depth 2 the upload of
+        batch s + 2 is already queued while batch s computes, so a slow transfer or a host hiccup does not idle the device;
+        results do not depend on it."""
         self.ctx = ctx
         self.upload = upload or ctx.upload_frames
         self.B = ctx.max_batch
+        if depth is None:
+            depth = 2 if (ctx.frame_slots >= min_frame_slots(self.B, 2) and ctx.flow_slots >= min_flow_slots(self.B, 2)) else 1
+        self.depth = int(depth)
+        if self.depth > 1 and (ctx.frame_slots < min_frame_slots(self.B, self.depth) or ctx.flow_slots < min_flow_slots(self.B, self.depth)):
+            raise ValueError(f"context too small for depth {self.depth}: need frame_slots >= {min_frame_slots(self.B, self.depth)} "
+                             f"and flow_slots >= {min_flow_slots(self.B, self.depth)}")
         # frame slots: a batch's <= B+1 (stream) / 2B (arbitrary pairs) frames + the next batch's new ones;
         # flow slots: two batches in flight + the <= 6 pairs still waiting for their +-6 window (2B + 6 live
         # at most; 2B + 13 is the bound ffl.h documents and Context defaults to)
@@ -146,14 +162,13 @@ class PairEngine:
             if on_batch:
                 on_batch(ls, js, got)
 
-        pending = None
+        pending, depth = [], getattr(self, "depth", 1)
         for l0 in range(0, len(pairs), B):
-            cur = enqueue(l0)
-            if pending:
-                collect(*pending)
-            pending = cur
-        if pending:
-            collect(*pending)
+            pending.append(enqueue(l0))
+            if len(pending) > depth:
+                collect(*pending.pop(0))
+        while pending:
+            collect(*pending.pop(0))
         return recs
 
     def process_chunk(self, frames, pov_mode=False, cut_threshold=7.0):

@@ -228,6 +228,17 @@ def test_pair_engine_frame_ring_and_slot_bounds():
         got = [p for b in ctx.batches for p in b]
         assert [(a, b) for a, b, _ in got] == [(j, j + 1) for j in mine] and [s for _, _, s in got] == list(range(len(mine)))
     assert pipeline.min_flow_slots(8) == 2 * 8 + 13
+    # depth 2 (two batches queued ahead of the one being collected) is chosen when the context has the slots for it, gives
+    # the same batches, and still uploads every frame of a stream exactly once
+    ctx = _FakeCtx(4, pipeline.min_frame_slots(4, 2), pipeline.min_flow_slots(4, 2))
+    eng = pipeline.PairEngine(ctx)
+    assert eng.depth == 2 and (ctx.frame_slots, ctx.flow_slots) == (15, 25)
+    eng.pass1(frames, 0, 39)
+    got = [p for b in ctx.batches for p in b]
+    assert [(a, b) for a, b, _ in got] == [(j, j + 1) for j in range(39)] and sum(n for _, n in ctx.uploads) == 40
+    assert pipeline.PairEngine(_FakeCtx(4, 10, 21)).depth == 1
+    with pytest.raises(ValueError):
+        pipeline.PairEngine(_FakeCtx(4, 10, 21), depth=2)
     with pytest.raises(ValueError):
         pipeline.PairEngine(_FakeCtx(4, 9, 64))               # frame slots < 2B + 2
     with pytest.raises(ValueError):
