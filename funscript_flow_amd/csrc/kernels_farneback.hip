@@ -865,11 +865,6 @@ __device__ __forceinline__ void k_polyexp_body(const unsigned bx, const unsigned
             const int gy = min(max(y0 + ly - PE_N, 0), h - 1), gx = x0 + lx - PE_N;
             const float *row = img + (size_t)gy * w;
             float4 t;
-#ifdef FFL_EXP_PE_NOLOAD   // timing-only: the tile is synthesised, no global load (what is left is LDS + vector work + stores)
-            if (w > 0) {
-                t = make_float4((float)gx, (float)gy, (float)(gx ^ gy), 1.f);
-            } else
-#endif
             if (gx >= 0 && gx + 3 < w) {
                 const ffl_f4u q = *reinterpret_cast<const ffl_f4u *>(row + gx);
                 t = make_float4(q.x, q.y, q.z, q.w);
@@ -968,16 +963,6 @@ __device__ __forceinline__ void k_polyexp_body(const unsigned bx, const unsigned
             o[4][e] = (float)(b6 * pc.ig55);
         }
         const size_t off = (size_t)y * w + x;
-#ifdef FFL_EXP_PE_NOSTORE  // timing-only: results are computed and dropped (never true)
-        {
-            float acc = 0.f;   // every output feeds the (never true) condition, so none of the arithmetic is dead
-#pragma unroll
-            for (int c = 0; c < 5; c++)
-#pragma unroll
-                for (int e = 0; e < 4; e++) acc += o[c][e];
-            if (acc != 1.2345e30f) return;
-        }
-#endif
         if (x + 3 < w) {
 #pragma unroll
             for (int c = 0; c < 5; c++) {
@@ -1203,8 +1188,10 @@ void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, c
 //   phase H  each lane owns 4 consecutive pixels of one row, wave q of the workgroup the q-th quarter
 //            of every 16-block (so the order of its additions is wave-uniform): 9 ds_read_b128 per
 //            channel bring the 18 column sums it needs;
-//   solve    2x2 system in double, float2 flow store (2 x dwordx4 per lane), fused UpdateMatrices
-//            with 8-byte R0 loads / M stores / R1 gathers.
+//   solve    2x2 system in double, the tile's displacements transposed through LDS; the level's last iteration
+//            stores the field (two pixels per lane, 16-byte stores), the updating iterations run the fused
+//            UpdateMatrices one pixel per lane with DWORD R0 loads / R1 corner gathers / M stores (a wave64 8-byte
+//            access costs the vector-memory path three dword accesses).
 // ------------------------------------------------------------------------------------------------
 #ifndef FFL_K5_WAVES
 #define FFL_K5_WAVES 4  // waves per SIMD the register allocator must leave room for (= workgroups per CU)
@@ -1306,10 +1293,6 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
     constexpr int GC = FIRST ? FFL_K5_GROUP_FIRST : FFL_K5_GROUP, NG = (5 + GC - 1) / GC;  // channels per LDS pass, passes
     __shared__ double2 sS2[GC][TH][LW2];
     const int tid = threadIdx.x;
-#ifdef FFL_EXP_LDSPAD
-    __shared__ float sPad[(UPDATE && !FIRST) ? FFL_EXP_LDSPAD / 4 : 1];   // timing-only: the LDS a fused stage would add
-    if (Min == nullptr && !FIRST) sPad[tid] = 1.f;
-#endif
 #ifdef FFL_STAMP
     __shared__ unsigned long long sStamp[FFL_NSTAMP + 1];
     const bool FFL_STAMP_ON = FIRST == 1 && w >= 1024;
@@ -1323,17 +1306,8 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
     // instead of 30 -- its halo re-reads (30 rows for 16 outputs) were the kernel's largest single cost.
     int b, tile_x, strip_y;  // XCD-aware panel order over the strips, see ffl_tile_coord
     const int tiles_y = (h + TH - 1) / TH;
-#ifdef FFL_EXP_S48
-    // TIMING-ONLY experiment (profiles/tools/exp_build.sh, results are wrong by design): what would the first stage of a
-    // fused "iteration 2 + 3" launch cost?  Such a stage computes a 64-wide window (x0 - 8 .. x0 + 55) for every 48 output
-    // columns and keeps its new M in LDS: here the updating launch runs on a 48-column tile pitch and stores nothing.
-    constexpr bool S48 = UPDATE && !FIRST;
-    if (!ffl_tile_coord(S48 ? (w + 47) / 48 : (w + TW - 1) / TW, (tiles_y + nrb - 1) / nrb, nB, order, b, tile_x, strip_y)) return;
-    const int x0 = S48 ? tile_x * 48 - 8 : tile_x * TW;
-#else
     if (!ffl_tile_coord((w + TW - 1) / TW, (tiles_y + nrb - 1) / nrb, nB, order, b, tile_x, strip_y)) return;
     const int x0 = tile_x * TW;
-#endif
     const float *Mb = Min + (size_t)b * M_stride;
 
     // phase H / solve: wave q owns quarter q of each 16-block; inside the wave 16 rows x 4 blocks
@@ -1606,8 +1580,8 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
                 float r0[5];
                 ffl_f2u t[5], u[5];
             };
-            const int lx = tid & 63, x = max(min(x0 + lx, w - 1), 0);
-            const bool xin = x0 + lx < w && x0 + lx >= 0;
+            const int lx = tid & 63, x = min(x0 + lx, w - 1);
+            const bool xin = x0 + lx < w;
             const float2 *sF2 = reinterpret_cast<const float2 *>(sF4);
             auto issue = [&](int k) {
                 UmRow S;
@@ -1645,11 +1619,7 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
                 for (int c = 0; c < 5; c++) bb[c] = cur.a00 * cur.t[c].x + cur.a01 * cur.t[c].y + cur.a10 * cur.u[c].x + cur.a11 * cur.u[c].y;
                 float m[5];
                 ffl_um_finish(cur.r0, bb, cur.inside, w, h, x, y, cur.f.x, cur.f.y, m);
-#ifdef FFL_EXP_S48
-                if (in && m[0] == 1.2345e30f) {   // never true: the arithmetic and its loads stay, the stores go
-#else
                 if (in) {
-#endif
 #pragma unroll
                     for (int c = 0; c < 5; c++) *ffl_at<float>(Mo + c * plane, o) = m[c];
                 }
@@ -1699,12 +1669,8 @@ static int ffl_blur_rows_per_wg(int tiles_x, int tiles_y, int nB) {
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
                            size_t plane, const PairTab *pt, int level, int nB, int lw, int lh, int update, int store_flow,
                            hipStream_t st) {
-    int tiles_x = (lw + 63) / 64;
-    const int tiles_y = (lh + 15) / 16;
+    const int tiles_x = (lw + 63) / 64, tiles_y = (lh + 15) / 16;
     const int nrb = g_blur_rows > 0 ? g_blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB);
-#ifdef FFL_EXP_S48
-    if (update) tiles_x = (lw + 47) / 48;
-#endif
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (update)
         hipLaunchKernelGGL((k_blur_solve<true, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, level, lw,

@@ -117,3 +117,15 @@ ORC_API void orc_rgb2gray(const uint8_t *rgb, int w, int h, int stride, uint8_t 
             gray[(size_t)y * w + x] = (uint8_t)((s[3 * x] * 9798 + s[3 * x + 1] * 19235 + s[3 * x + 2] * 3735 + 16384) >> 15);
     }
 }
+
+/* SENSITIVITY VARIANT (oracle/gen_sensitivity.py only): the 14-bit coefficient set of older OpenCV releases,
+ * gray = (R * 4899 + G * 9617 + B * 1868 + 8192) >> 14 -- SURVEY 8(f) rank 1 records that which of the two sets the
+ * pinned 4.11 wheel uses could not be verified here; results differ by at most 1 LSB.  The product and the default
+ * oracle use the 15-bit set above. */
+ORC_API void orc_rgb2gray14(const uint8_t *rgb, int w, int h, int stride, uint8_t *gray) {
+    for (int y = 0; y < h; y++) {
+        const uint8_t *s = rgb + (size_t)y * stride;
+        for (int x = 0; x < w; x++)
+            gray[(size_t)y * w + x] = (uint8_t)((s[3 * x] * 4899 + s[3 * x + 1] * 9617 + s[3 * x + 2] * 1868 + 8192) >> 14);
+    }
+}

@@ -155,6 +155,33 @@ def measure(W, H, seed, zoom, starts, variants=None, threads=8):
     return out
 
 
+def frontend_luma(pairs=16, src=(1280, 720), seed=5):
+    """The front-end's own unknown: 15-bit vs 14-bit luma coefficients.  Decoded BGR frames with
+    unequal channel gains -> resize to 256x256 + RGB2GRAY with either set -> the whole pair path; same metrics."""
+    W, H = src
+    # three different textures (one per colour channel) under the same motion: channel values are independent, so the two
+    # coefficient sets do round differently at some pixels (proportional channels never reach a rounding boundary)
+    bgr = np.stack([sine_translate_frames(pairs + 1, W, H, seed=seed + c, zoom=0.03) for c in range(3)], axis=-1)
+    f15 = [orc.frontend(f, False, (256, 256)) for f in bgr]
+    f14 = [orc.frontend(f, False, (256, 256), luma14=True) for f in bgr]
+    differing = float(np.mean([np.mean(a != b) for a, b in zip(f15, f14)]))
+    maxdiff = int(max(np.abs(a.astype(int) - b).max() for a, b in zip(f15, f14)))
+    base = [orc.farneback(f15[j], f15[j + 1]) for j in range(pairs)]
+    var = [orc.farneback(f14[j], f14[j + 1]) for j in range(pairs)]
+    brecs, bcs, bdots = post(base)
+    recs, cs, dots = post(var)
+    bdiv = [orc.divergence_c(f) for f in base]
+    scales = [max(abs(d), weighted_dot_scale(f, c)) for f, c, d in zip(base, bcs, bdots)]
+    return {"source": list(src), "pairs": pairs, "gray_pixels_differing": differing, "gray_max_abs_diff": maxdiff,
+            "margin_top1_top2": [top2_margin(d) for d in bdiv],
+            "flow_max_abs_delta": [float(np.abs(a - b).max()) for a, b in zip(var, base)],
+            "flow_mean_abs_delta": [float(np.abs(a.astype(np.float64) - b).mean()) for a, b in zip(var, base)],
+            "div_max_abs_delta": [float(np.abs(orc.divergence_c(a) - d).max()) for a, d in zip(var, bdiv)],
+            "argmax_moved": [bool((r[0], r[1]) != (b[0], b[1])) for r, b in zip(recs, brecs)],
+            "mean_mag_rel_delta": [abs(r[3] - b[3]) / b[3] for r, b in zip(recs, brecs)],
+            "scalar_rel_delta": [abs(d - b) / s for d, b, s in zip(dots, bdots, scales)]}
+
+
 def margin_survey(seeds=range(20, 28), W=256, H=256, pairs=16, threads=8):
     """top-1 - top-2 |div| margins of many more pairs of the default oracle (no variants): how often is a pair a near-tie?"""
     def one(seed):
@@ -191,10 +218,15 @@ def main():
            "fma_variants_measured": orc.lib_fma() is not None,
            "min_margin_top1_top2": min(min(w["margin_top1_top2"]) for w in res.values()),
            "max_tie_flip_scalar_rel_delta": max(max(w["tie_flip"]["scalar_rel_delta"]) for w in res.values()),
-           "margin_survey": margin_survey(), "summary": summarize(res), "workloads": res}
+           "margin_survey": margin_survey(), "frontend_luma14_vs_15": frontend_luma(), "summary": summarize(res),
+           "workloads": res}
     with open(OUT, "w") as f:
         json.dump(doc, f, indent=1)
     print(json.dumps(doc["summary"], indent=1))
+    fl = doc["frontend_luma14_vs_15"]
+    print("frontend luma 14 vs 15 bit: gray pixels differing", fl["gray_pixels_differing"], "argmax moved", sum(fl["argmax_moved"]), "of",
+          fl["pairs"], "max scalar delta", max(fl["scalar_rel_delta"]), "max mean_mag delta", max(fl["mean_mag_rel_delta"]),
+          "flow max", max(fl["flow_max_abs_delta"]))
     print("margin survey", doc["margin_survey"])
     print("min margin", doc["min_margin_top1_top2"], "worst tie flip", doc["max_tie_flip_scalar_rel_delta"])
 

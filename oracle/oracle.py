@@ -82,6 +82,7 @@ def lib():
         L.orc_resize_linear_u8c3.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8p, C.c_int, C.c_int]
         L.orc_swap_rb.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8p]
         L.orc_rgb2gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8p]
+        L.orc_rgb2gray14.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, _u8p]
         L.orc_polyexp_prepare.argtypes = [_f32p, _f32p, _f32p, np.ctypeslib.ndpointer(np.float64)]
         L.orc_polyexp.argtypes = [_f32p, C.c_int, C.c_int, _f32p]
         L.orc_flow_upsample.argtypes = [_f32p, C.c_int, C.c_int, _f32p, C.c_int, C.c_int]
@@ -153,16 +154,17 @@ def resize_linear_u8c3(img, dw, dh):
     return out
 
 
-def rgb2gray(img):
-    """cv2.cvtColor(img, cv2.COLOR_RGB2GRAY) on an (h, w, 3) view (rows may be strided)   FF:1079, FF:1082"""
+def rgb2gray(img, luma14=False):
+    """cv2.cvtColor(img, cv2.COLOR_RGB2GRAY) on an (h, w, 3) view (rows may be strided)   FF:1079, FF:1082
+    luma14: the 14-bit coefficient set of older OpenCV releases (sensitivity study only)."""
     h, w, _ = img.shape
     out = np.empty((h, w), np.uint8)
     a, st = _rows_view(img)
-    lib().orc_rgb2gray(a.ctypes.data, w, h, st, out)
+    (lib().orc_rgb2gray14 if luma14 else lib().orc_rgb2gray)(a.ctypes.data, w, h, st, out)
     return out
 
 
-def frontend(frame_bgr, vr_mode=False, size=(256, 256)):
+def frontend(frame_bgr, vr_mode=False, size=(256, 256), luma14=False):
     """Decoded BGR frame -> the gray operand of the pair kernel, step by step as the reference does it:
     BGR2RGB (FF:182); non-VR: resize to `size` unless already that size (FF:185-186, FF:1057) then RGB2GRAY
     (FF:1082); VR: resize to twice `size`, keep rows [h:], columns [:w] (FF:1076-1079), RGB2GRAY."""
@@ -170,10 +172,10 @@ def frontend(frame_bgr, vr_mode=False, size=(256, 256)):
     rgb = swap_rb(frame_bgr)
     if vr_mode:
         r = resize_linear_u8c3(rgb, 2 * w, 2 * h)
-        return rgb2gray(r[h:, :w])
+        return rgb2gray(r[h:, :w], luma14)
     if rgb.shape[1] != w or rgb.shape[0] != h:
         rgb = resize_linear_u8c3(rgb, w, h)
-    return rgb2gray(rgb)
+    return rgb2gray(rgb, luma14)
 
 
 def pyr_level(img, k):
