@@ -510,6 +510,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
     if args.rehearse_gloo:
         local_rank = 0
+    if torch.cuda.device_count() <= local_rank:
+        print(f"bench.py: FATAL rank {rank}/{world}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} visible GPU(s); "
+              f"one rank per GPU is required (use --rehearse-gloo only for single-GPU rehearsals)", file=sys.stderr, flush=True)
+        os._exit(3)
     torch.cuda.set_device(local_rank)
     host_group = None
     if world > 1:
@@ -523,10 +527,8 @@ def main():
             # a real collective on the device, so that a broken RCCL / xGMI setup ends the run with one clear message and a
             # non-zero exit code before anything is timed -- never a silent switch to another backend.
             try:
-                if torch.cuda.device_count() <= local_rank:
-                    raise RuntimeError(f"LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} visible GPUs")
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                        timeout=datetime.timedelta(seconds=300))
+                                        timeout=datetime.timedelta(seconds=180))
                 probe = torch.ones(1, device="cuda") * (rank + 1)
                 dist.all_reduce(probe, op=dist.ReduceOp.SUM)
                 torch.cuda.synchronize()

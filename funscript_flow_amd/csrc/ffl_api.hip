@@ -199,7 +199,7 @@ struct ffl_ctx {
     };
     RawBuf raw[FFL_RAW_RING];
     unsigned raw_next = 0;
-    hipEvent_t post_ring[FFL_EV_RING] = {nullptr};  // events of ffl_upload_flow (s_post)
+    hipEvent_t post_ring[FFL_EV_RING] = {nullptr};  // events of ffl_upload_flow and ffl_radial (s_post); a ring, so a handle an old slot still holds only ever points to later work of that stream
     unsigned post_next = 0;
     // flow slots
     float *d_flow = nullptr;          // [n_slots][2N]
@@ -1252,6 +1252,13 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
         HIPCHK(c, hipMemcpyAsync(c->d_rtab, &rt, sizeof(RadialTab), hipMemcpyHostToDevice, st));
         ProfScope ps(c, FFL_K_RADIAL, st);
         ffl_launch_radial(c->d_rtab, m, c->w, c->h, pov_mode, c->d_wytab, c->d_rpsum, c->d_radial, st);
+    }
+    {
+        // the slots' "last use" now includes this pass 2: the wait below runs without the context lock, so another thread
+        // may queue a batch that recycles one of these slots meanwhile -- it must run behind the kernel that reads them
+        hipEvent_t ev = c->post_ring[c->post_next++ % FFL_EV_RING];
+        HIPCHK(c, hipEventRecord(ev, st));
+        for (int j = 0; j < m; j++) c->ev_slot_done[slots[map[j]]] = ev;
     }
     lk.unlock();  // the wait (for the batches the slots come from, then pass 2) does not hold up uploads / submissions
     hipError_t se = hipStreamSynchronize(st);  // k_radial_final stored into the mapped pinned buffer
