@@ -458,6 +458,7 @@ def main():
                     help="minimum tiles x pairs of a level for folding its initial UpdateMatrices into the first blur+solve "
                          "launch (library default 10000; 0: never, 1: always)")
     ap.add_argument("--blur-rows", type=int, default=0, help="tiles a k_blur_solve workgroup walks down (0 = automatic)")
+    ap.add_argument("--blur-min-wgs", type=int, default=0, help="automatic strip length of k_blur_solve: longest strips that still give this many workgroups (library default 4000)")
     ap.add_argument("--tile-order", type=int, default=-1, help="k_blur_solve / k_update_matrices tile order (ffl_set_option)")
     ap.add_argument("--trace-steps", action="store_true", help="print per-step host wall times to stderr")
     ap.add_argument("--lanes", type=int, default=0, help="compute lanes (co-scheduled batches) per context, default 1")
@@ -549,6 +550,8 @@ def main():
         FUSE_FIRST = args.fuse_first
     if args.blur_rows:
         _capi.set_option("blur_rows", args.blur_rows)
+    if args.blur_min_wgs:
+        _capi.set_option("blur_min_wgs", args.blur_min_wgs)
     if args.tile_order >= 0:
         _capi.set_option("tile_order", args.tile_order)
     # One compute lane by default: kernels of consecutive batches then run back to back, so the

@@ -1369,6 +1369,11 @@ static int set_option_impl(const char *name, int value) {
         ffl_set_blur_rows(value);
         return FFL_OK;
     }
+    if (!strcmp(name, "blur_min_wgs")) {  // automatic strip length: the longest strips that still give this many workgroups
+        if (value < 1) return FFL_ERR_INVALID;
+        ffl_set_blur_min_wgs(value);
+        return FFL_OK;
+    }
     if (!strcmp(name, "tile_order")) {  // 0 pair-major, 1 tile-major (ffl_tile_coord)
         if (value < 0 || value > 1) return FFL_ERR_INVALID;
         ffl_set_tile_order(value);

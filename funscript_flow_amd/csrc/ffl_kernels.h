@@ -122,6 +122,7 @@ void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const
 void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane,
                                  const PairTab *pt, int level, int nB, int lw, int lh, int pw, int ph, hipStream_t st);
 void ffl_set_blur_rows(int n);  // tiles a k_blur_solve workgroup walks down (0 = automatic)
+void ffl_set_blur_min_wgs(int n);  // automatic strip length: the longest strips that still give this many workgroups
 void ffl_set_pyr_coarse(int on);    // 1 (default): one-pass kernel for the x1/4 and x1/8 pyramid levels where sizes allow
 void ffl_set_tile_order(int order);  // 0 pair-major, 1 tile-major (see ffl_tile_coord)
 

@@ -1657,13 +1657,22 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
 #endif
 }
 
-// tiles a workgroup walks down: as many as still leave the device about four rounds of workgroups
-// (1080p, B = 8, level 0: 4 -> 310 / 128 us fused / un-fused against 334 / 145 us with one tile per
-// workgroup; with fewer workgroups than that the coarse levels lose more to idle CUs than they gain)
+// Tiles a workgroup walks down.  The strip walk saves 14 of 30 row loads per tile after a strip's first, so long strips
+// are cheaper -- as long as the launch still has enough workgroups to fill the device for several rounds.  A column of
+// tiles_y tiles is cut into s equal strips (nrb = ceil(tiles_y / s)), with the smallest s that gives at least
+// g_blur_min_wgs workgroups (ffl_set_option "blur_min_wgs").  Same-box interleaved sweep (profiles/r03_c_strip_sweep.txt,
+// pairs/s against the threshold 8000, which is about what the power-of-two rule of rounds 1-2 chose): 1080p B = 32:
+// 2500 -3.0 %, 3000 +1.4, 3400-3840 +1.8, 4000 +0.6; 3840x2160 B = 32: 3000-3500 +2.8, 4000 +2.4, 6000 -0.1; 256x256
+// B = 256: 3000 -14.5 (a level lands on exactly 3072 workgroups), 3500-4000 +1.5, 6000 -2.2.
+static int g_blur_min_wgs = 3500;
+void ffl_set_blur_min_wgs(int n) { g_blur_min_wgs = n; }
 static int ffl_blur_rows_per_wg(int tiles_x, int tiles_y, int nB) {
-    int nrb = 8;
-    while (nrb > 1 && (long)tiles_x * ((tiles_y + nrb - 1) / nrb) * nB < 4000) nrb >>= 1;
-    return nrb;
+    for (int s = 1; s <= tiles_y; s++) {
+        const int nrb = (tiles_y + s - 1) / s;
+        if (nrb > 64) continue;
+        if ((long)tiles_x * ((tiles_y + nrb - 1) / nrb) * nB >= g_blur_min_wgs || nrb == 1) return nrb;
+    }
+    return 1;
 }
 
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,

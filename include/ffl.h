@@ -170,6 +170,8 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
  *                            is anchored to blocks of 16 rows / columns (other values are refused); the
  *                            8 / 16 / 32 sweep of BASELINE configs[2] is recorded in profiles/README.md
  *   "blur_rows"   = 0..64    tiles a k_blur_solve workgroup walks down (0 = automatic, the default)
+ *   "blur_min_wgs" = N >= 1  automatic strip length: a column of tiles is cut into the fewest equal strips that still
+ *                            give the launch N workgroups (default 3500)
  *   "fuse_first"  = N >= 0   a level's flow init + first UpdateMatrices run inside its first k_blur_solve launch
  *                            when the level has at least N 64x16 tiles over the batch (default 10000; 0 = never,
  *                            1 = always)
