@@ -32,7 +32,7 @@ for line in open(os.path.join(P, f"{tag}_kernel_trace_by_grid.txt")):
     m = re.match(r"(\S.*?)\s+\((\d+), 1, 1\)\s+(\d+)\s+([\d.]+)", line)
     if m:
         grid[(m.group(1).strip(), int(m.group(2)))] = float(m.group(4))
-l0 = max(g for (k, g) in grid if k.startswith("k_blur_solve<true, 1>"))
+l0 = max(((v, g) for (k, g), v in grid.items() if k.startswith("k_blur_solve<true, 1>")))[1]   # level 0 = the longest folded launch
 tj = json.load(open(os.path.join(P, "traffic.json")))["workloads"]["1920x1080_b32"]
 pmc = {}
 for line in open(os.path.join(P, f"{tag}_pmc_fetch_write.txt")):
