@@ -367,8 +367,9 @@ def test_bench_prints_exactly_one_json_line():
 
 
 def test_non_default_options_change_no_bit():
-    """tile_order = 1 (tile-major workgroup order), pyr_coarse = 0 (H + V kernel pairs for the coarse pyramid levels) and
-    copy_threads = 1 / 8 (staging copy split) are speed options: records, scalars and the flow field must be identical."""
+    """tile_order = 1 (tile-major workgroup order), pyr_coarse = 0 (H + V kernel pairs for the coarse pyramid levels),
+    copy_threads = 1 / 8 (staging copy split) and blur_min_wgs (automatic strip length of k_blur_solve, from a whole tile
+    column per workgroup to one tile) are speed options: records, scalars and the flow field must be identical."""
     from funscript_flow_amd.synth import gray_to_bgr
     w, h, B = 640, 360, 8
     frames = sine_translate_frames(B + 1, w, h, seed=21, amp=(3.0, 2.0), period=7, zoom=0.02)
@@ -391,9 +392,11 @@ def test_non_default_options_change_no_bit():
             _capi.set_option("tile_order", 0)
             _capi.set_option("pyr_coarse", 1)
             _capi.set_option("copy_threads", 4)
+            _capi.set_option("blur_min_wgs", 3500)
 
     ref = run()
-    for opts in ({"tile_order": 1}, {"pyr_coarse": 0}, {"copy_threads": 1}, {"copy_threads": 8}, {"tile_order": 1, "fuse_first": 1}):
+    for opts in ({"tile_order": 1}, {"pyr_coarse": 0}, {"copy_threads": 1}, {"copy_threads": 8}, {"tile_order": 1, "fuse_first": 1},
+                 {"blur_min_wgs": 1}, {"blur_min_wgs": 200}, {"blur_min_wgs": 100000}):   # one strip per column ... one tile per workgroup
         try:
             got = run(**opts)
         finally:

@@ -206,7 +206,7 @@ def test_folded_first_iteration_bit_exact(w, h):
         assert np.array_equal(got[j], orc.farneback(fr[j], fr[j + 1]))
 
 
-@pytest.mark.parametrize("rows,fuse", [(2, 0), (3, 1), (8, 0), (8, 1)])
+@pytest.mark.parametrize("rows,fuse", [(2, 0), (3, 1), (8, 0), (8, 1), (17, 1), (23, 0)])
 def test_strip_walk_bit_exact(rows, fuse):
     """blur_rows forces how many vertically adjacent tiles a k_blur_solve workgroup walks down (carrying 14 rows in
     registers); automatic selection only exceeds 1 on large grids.  Heights that are / are not multiples of
@@ -214,7 +214,7 @@ def test_strip_walk_bit_exact(rows, fuse):
     try:
         _capi.set_option("blur_rows", rows)
         _capi.set_option("fuse_first", fuse)
-        for (w, h) in [(250, 131), (320, 180), (96, 80), (64, 256)]:
+        for (w, h) in [(250, 131), (320, 180), (96, 80), (64, 256), (80, 560)]:       # 35 tile rows: 17 + 17 + 1, 23 + 12
             fr = frames(2, w, h, seed=rows * 10 + fuse, amp=(2.0, 3.0), period=5)
             with _capi.Context(w, h, max_batch=1) as ctx:
                 ctx.submit_pair(0, fr[0], fr[1])
