@@ -306,3 +306,39 @@ def test_kernel_resource_budgets(tmp_path):
         assert vgpr <= 128 and lds <= 160 * 1024 // 4, (upd, vgpr, lds)
     vgpr, _, lds = one("_Z15k_polyexp_multi")
     assert vgpr <= 80 and lds <= 160 * 1024 // 6, (vgpr, lds)   # 6 workgroups per CU (LDS alone would allow 7)
+
+
+def test_bench_helpers_without_a_gpu(tmp_path, monkeypatch):
+    """bench.py's bookkeeping that needs no device: algorithmic bytes per kernel class (SURVEY 8(d) stage graph), the
+    traffic lookup keyed by workload and tied to the kernel signature, and the process-pool CPU baseline on a tiny frame."""
+    import importlib
+    import json
+    bench = importlib.import_module("bench")
+    N, B, U = 1920 * 1080, 32, 33
+    levels = [(1920, 1080), (960, 540), (480, 270), (240, 135)]
+    alg = bench.alg_bytes_per_batch(N, B, U, levels)
+    s = sum(w * h for w, h in levels)
+    assert alg["k_polyexp"] == U * 24 * s and alg["k_pass1"] == alg["k_radial"] == B * 8 * N
+    # levels 0 and 1 are folded at B = 32 (>= 10000 tiles): their flow-init + UpdateMatrices_0 bytes sit on k_blur_solve
+    folded = sum(78.0 * w * h for w, h in levels[:2])
+    assert alg["k_blur_solve"] == B * (220.0 * s + folded)
+    assert abs(sum(alg.values()) / B - 941.9e6) < 0.1e6          # the whole-path figure DESIGN.md quotes (stream form)
+    # traffic entries: right workload + right signature only
+    tj = {"workloads": {"1920x1080_b32": {"kernel": "k_blur_solve", "kernel_signature": bench.kernel_signature(), "fuse_first": 10000,
+                                          "hbm_bytes_per_launch": 123.0, "captured": "t"},
+                        "256x256_b256": {"kernel": "k_blur_solve", "kernel_signature": "stale", "hbm_bytes_per_launch": 1.0}}}
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    (prof / "traffic.json").write_text(json.dumps(tj))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_signature", lambda: tj["workloads"]["1920x1080_b32"]["kernel_signature"])
+    assert bench.load_traffic(1920, 1080, 32, "k_blur_solve")[0] == 123.0
+    assert bench.load_traffic(256, 256, 256, "k_blur_solve")[0] is None and "stale" in bench.load_traffic(256, 256, 256, "k_blur_solve")[1]
+    assert bench.load_traffic(3840, 2160, 32, "k_blur_solve")[0] is None
+    r = bench.roofline_block({"k_blur_solve": (12, 4.0)}, {"k_blur_solve": 2.0e9}, 1, 1920, 1080, 32, "k_blur_solve")
+    assert abs(r["achieved"] - 500.0) < 1e-9 and r["traffic"] == 123.0 and r["launches"] == 12
+    monkeypatch.undo()
+    from funscript_flow_amd.synth import sine_translate_frames
+    c = bench.cpu_baseline(sine_translate_frames(5, 96, 64, seed=1), max_workers=2, pairs_per_worker=2)
+    assert c["kind"] == "port" and c["value"] > 0 and c["single_thread"] > 0 and set(c["sweep"]) >= {"1", "2"}
+    assert c["cores"] in (1, 2) and "FF:1190-1191" in c["sample"]
