@@ -173,6 +173,10 @@ def test_sharded_two_pass_gloo_world8_with_empty_and_one_pair_shards(tmp_path):
     """8 ranks (north_star's widest configuration) on FEWER pairs than 2 x ranks: 5 pairs leave three ranks with an empty
     shard under every assignment (they must still take part in both gathers), 11 pairs give shards of one and two pairs;
     the +-6 smoothing window then spans every shard.  Results must equal the single-process chunk exactly."""
+    if os.path.exists("/dev/kfd"):
+        # a GPU box: every rank's `import torch` opens the device node, and the pool's boxes admit at most 6 processes on a
+        # card (an 8-rank run is killed by their process guard) -- this CPU-only test belongs to the GPU-less suite
+        pytest.skip("world-8 gloo test runs where no GPU device node exists (the GPU boxes cap processes per card at 6)")
     _run_sharded(tmp_path, 8, 6, 29573)
     _run_sharded(tmp_path, 8, 12, 29575)
 
