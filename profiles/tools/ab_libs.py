@@ -1,7 +1,9 @@
 """Same-box, same-process A/B of two BUILDS of libffl_hip.so (kernel code variants): both libraries are loaded side by
 side (two copies of the ctypes binding), each gets its own context on the same resident frames, and the two are stepped
 alternately; per build the median over the rounds of (wall ms per step, k_blur_solve ms per step) and a check that both
-give identical records.  Resolution ~0.2 % where separate bench runs differ by 3-5 % box to box.
+give identical records.  Rounds repeat to ~0.2 %, but every build has its own context, i.e. its own buffer placement, and
+identical builds have been seen 1.75 % apart (profiles/r03_c_ab_noise_floor_and_panel_width.txt): trust differences above
+~2 %, load a build twice to see the floor, and prefer strip_sweep.py (one context) for launch-geometry options.
 Usage: python profiles/tools/ab_libs.py /path/libA.so /path/libB.so [more.so ...]      env WHB=1920,1080,32 STEPS ROUNDS"""
 import importlib.util
 import os
