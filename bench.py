@@ -85,31 +85,31 @@ def alg_bytes_per_batch(N, B, U, level_sizes):
     }
 
 
-def _cpu_worker(frames, w, h, jobs, barrier, q):
+def _cpu_worker(frames, w, h, jobs, barrier, q, fast):
     """One worker PROCESS of the cpu_baseline pool (forked before any GPU call): its own pre-faulted workspace, so the
     timed loop neither mallocs nor first-touches a page; starts on a barrier shared by the whole pool."""
     try:
         import oracle as orc
-        ws = orc.PairWorkspace(w, h)
+        ws = orc.PairWorkspace(w, h, fast)
         n = len(frames) - 1
         barrier.wait(timeout=300)
         t0 = time.perf_counter()              # CLOCK_MONOTONIC: comparable across the pool's processes
         for j in jobs:
             flow, x, y, v, mm = ws.pair(frames[j % n], frames[j % n + 1])
-            orc.radial_c(flow, (w / 2.0, h / 2.0), mm > 7, False)
+            ws.radial((w / 2.0, h / 2.0), mm > 7, False)
         q.put((t0, time.perf_counter(), len(jobs)))
     except BaseException as e:  # noqa: BLE001
         q.put(("error", repr(e), 0))
 
 
-def _cpu_pool_rate(frames, workers, pairs_per_worker):
+def _cpu_pool_rate(frames, workers, pairs_per_worker, fast=False):
     """pairs/s of `workers` processes x `pairs_per_worker` pairs each: all pairs / (last end - first start)."""
     import multiprocessing as mp
     ctx = mp.get_context("fork")
     h, w = frames[0].shape
     barrier, q = ctx.Barrier(workers), ctx.Queue()
     procs = [ctx.Process(target=_cpu_worker, daemon=True,
-                         args=(frames, w, h, [i * pairs_per_worker + k for k in range(pairs_per_worker)], barrier, q))
+                         args=(frames, w, h, [i * pairs_per_worker + k for k in range(pairs_per_worker)], barrier, q, fast))
              for i in range(workers)]
     for p in procs:
         p.start()
@@ -134,10 +134,18 @@ def cpu_baseline(frames, max_workers=None, pairs_per_worker=2):
     Pool(processes=threads).starmap), each running the C oracle ('port': Farneback + argmax + mean magnitude + radial) on
     the same synthetic stream.  MUST run before the first HIP call of this process (fork is only safe then): main() calls
     it before `import torch`.  Measures 1 worker, then 16 / 64 / os.cpu_count() workers (those that fit) so that the knee
-    is visible; `value` is the best point of the sweep."""
+    is visible; `value` is the best point of the sweep.
+
+    Two builds of the same C source are timed.  `value` (and the sweep) come from liboracle_fast.so: -O3 -march=native of
+    the host it runs on, FMA contraction and vectorisation allowed -- the reference's CPU path is cv2's SIMD wheel
+    (FF:878-879), so the stated baseline should not be handicapped by the flags bit parity needs.  `value_parity_build`
+    is liboracle.so (-O2 -ffp-contract=off, the build every parity test checks against) at the same worker count, and
+    `max_abs_dflow_fast_vs_parity` says how far the fast build's flow is from it on the first timed pairs.  The fast
+    build is never used as a checker."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as orc
     orc.lib()                                   # build + load once, the workers inherit it
+    fast = orc.lib_fast() is not None
     h, w = frames[0].shape
     cores = os.cpu_count() or 1
     try:
@@ -151,13 +159,13 @@ def cpu_baseline(frames, max_workers=None, pairs_per_worker=2):
     except Exception:  # noqa: BLE001
         fit = cores
     top = min(max_workers or cores, cores, fit)
-    single, sdt = _cpu_pool_rate(frames, 1, max(pairs_per_worker, 2))
+    single, sdt = _cpu_pool_rate(frames, 1, max(pairs_per_worker, 2), fast)
     sweep = {"1": {"pairs_per_s": single, "per_worker": single, "wall_s": sdt}}
     stopped = None
     for n in sorted({min(16, top), min(64, top), top}):
         if n <= 1:
             continue
-        v, dt = _cpu_pool_rate(frames, n, pairs_per_worker)
+        v, dt = _cpu_pool_rate(frames, n, pairs_per_worker, fast)
         sweep[str(n)] = {"pairs_per_s": v, "per_worker": v / n, "wall_s": dt}
         if v / n < single / 3.0 and n < top:
             # the pool is past the knee (a worker gets less than a third of a core: the box's CPU quota or memory system is
@@ -167,23 +175,44 @@ def cpu_baseline(frames, max_workers=None, pairs_per_worker=2):
             break
     best = max(sweep, key=lambda k: sweep[k]["pairs_per_s"])
     widest = max(sweep, key=int)
+    wall = sum(v["wall_s"] for v in sweep.values())
+    parity = {}
+    if fast:
+        # the parity build at the two points that matter (one worker, the best worker count), and the distance of the two
+        # builds' results on the first two timed pairs (computed here, in the parent, which has not touched the GPU)
+        ps, pdt = _cpu_pool_rate(frames, 1, max(pairs_per_worker, 2), False)
+        pb, pbdt = (ps, 0.0) if int(best) == 1 else _cpu_pool_rate(frames, int(best), pairs_per_worker, False)
+        wall += pdt + pbdt
+        a, b = orc.PairWorkspace(w, h, True), orc.PairWorkspace(w, h, False)
+        dmax, same_argmax = 0.0, True
+        for j in range(min(2, len(frames) - 1)):
+            fa, xa, ya, _, _ = a.pair(frames[j], frames[j + 1])
+            fb, xb, yb, _, _ = b.pair(frames[j], frames[j + 1])
+            dmax = max(dmax, float(np.max(np.abs(fa - fb))))
+            same_argmax = same_argmax and (xa, ya) == (xb, yb)
+        parity = {"value_parity_build": pb, "single_thread_parity_build": ps, "fast_over_parity": sweep[best]["pairs_per_s"] / pb,
+                  "max_abs_dflow_fast_vs_parity": dmax, "argmax_equal_fast_vs_parity": same_argmax}
     quota = None
     try:                                         # cgroup v2 CPU quota of the box, if any: "max" or "<quota> <period>"
         q, per = open("/sys/fs/cgroup/cpu.max").read().split()
         quota = None if q == "max" else float(q) / float(per)
     except Exception:  # noqa: BLE001
         pass
-    return {"value": sweep[best]["pairs_per_s"], "unit": "pairs/s", "cores": int(best), "kind": "port",
-            "host_cores": cores, "usable_cores": usable, "cpu_quota_cores": quota, "single_thread": single,
-            "per_worker_vs_single_at_value": sweep[best]["per_worker"] / single,
-            "widest": {"workers": int(widest), "pairs_per_s": sweep[widest]["pairs_per_s"], "per_worker": sweep[widest]["per_worker"],
-                       "per_worker_vs_single": sweep[widest]["per_worker"] / single},
-            "sweep": sweep, "sweep_note": stopped,
-            "sample": f"{w}x{h} pairs of the same synthetic stream; a pool of worker PROCESSES as the reference's "
-                      f"Pool(processes=threads).starmap (FF:1190-1191), forked before any GPU call, one pre-faulted workspace "
-                      f"per worker (no malloc / page fault in the timed loop), {pairs_per_worker} pairs per worker, barrier "
-                      f"start; C oracle (Farneback + argmax + mean magnitude + radial); `value` = best point of the sweep "
-                      f"({best} workers), `cores` = its worker count; total {sum(v['wall_s'] for v in sweep.values()):.1f} s wall"}
+    out = {"value": sweep[best]["pairs_per_s"], "unit": "pairs/s", "cores": int(best), "kind": "port",
+           "build": ("liboracle_fast.so: gcc -O3 -march=native -ffp-contract=fast of the oracle source, built on this host (timing only)"
+                     if fast else "liboracle.so: gcc -O2 -ffp-contract=off (the parity build; the -O3 -march=native build could not be made here)"),
+           "host_cores": cores, "usable_cores": usable, "cpu_quota_cores": quota, "single_thread": single,
+           "per_worker_vs_single_at_value": sweep[best]["per_worker"] / single,
+           "widest": {"workers": int(widest), "pairs_per_s": sweep[widest]["pairs_per_s"], "per_worker": sweep[widest]["per_worker"],
+                      "per_worker_vs_single": sweep[widest]["per_worker"] / single},
+           "sweep": sweep, "sweep_note": stopped,
+           "sample": f"{w}x{h} pairs of the same synthetic stream; a pool of worker PROCESSES as the reference's "
+                     f"Pool(processes=threads).starmap (FF:1190-1191), forked before any GPU call, one pre-faulted workspace "
+                     f"per worker (every page of scratch and output touched before the barrier), {pairs_per_worker} pairs per "
+                     f"worker, barrier start; C oracle (Farneback + argmax + mean magnitude + radial); `value` = best point of "
+                     f"the sweep ({best} workers), `cores` = its worker count; total {wall:.1f} s wall"}
+    out.update(parity)
+    return out
 
 
 class StepRunner:
@@ -263,10 +292,19 @@ def resident_pass(W, H, B, steps, warmup, device, seed, events, independent=Fals
     return dt, prof, runner, frames, level_sizes, U, ctx
 
 
+def _golden_check():
+    """tests/golden_check.py: the comparison with the committed oracle goldens (test infrastructure, kept beside them)."""
+    tdir = os.path.join(ROOT, "tests")
+    if tdir not in sys.path:
+        sys.path.insert(0, tdir)
+    import golden_check
+    return golden_check
+
+
 def verify(runner, frames, W, H, B, seed, ctx):
     """Timed steps vs the oracle goldens: every step must give the same records and scalars (same inputs), the
     last one is compared number by number, its flow slots are still resident for the crc check."""
-    from funscript_flow_amd import golden_check
+    golden_check = _golden_check()
     gold = golden_check.load_golden(W, H, B, seed)
     if gold is None or not runner.results:
         return None, "no golden file for this workload (oracle/gen_bench_golden.py W H B seed)"
@@ -361,7 +399,7 @@ def large_image(W, H, B, steps, warmup, device, seed, what):
             "checked": chk[0], "check_detail": chk[1]}
 
 
-def one_clip(args, rank, world, local_rank, host_group, barrier, torch, dist):
+def one_clip(args, rank, world, local_rank, host_group, barrier, max_over_ranks, dist):
     """north_star's wording: the pairs of ONE clip dealt round-robin over the GPUs (strong scaling of a chunk).
 
     The clip is steps x batch x N pairs of the seed-1 stream (host ndarrays: 17 distinct frames, cycled); every rank runs
@@ -385,34 +423,60 @@ def one_clip(args, rank, world, local_rank, host_group, barrier, torch, dist):
         dist.all_gather_object(out, obj, group=host_group)
         return out
 
+    def chunk(fr):
+        if args.assign == "contiguous":      # streaming form: only the 6 + 6 halo records cross between the passes
+            return pipeline.process_chunk_sharded_halo(eng, fr, rank, world, allgather)
+        return pipeline.process_chunk_sharded(eng, fr, rank, world, allgather, assign=args.assign, block=args.rr_block)
+
     with _capi.Context(W, H, device=local_rank, max_batch=B, frame_slots=2 * B + 2, flow_slots=max(len(mine), 1)) as ctx:
         eng = pipeline.HipShardEngine(ctx)
-        warm = frames[:min(n_pairs, 2 * B * world) + 1]
-        pipeline.process_chunk_sharded(eng, warm, rank, world, allgather, assign=args.assign, block=args.rr_block)
+        chunk(frames[:min(n_pairs, 2 * B * world) + 1])    # warm-up
         barrier()
         t0 = time.perf_counter()
-        dots, recs = pipeline.process_chunk_sharded(eng, frames, rank, world, allgather, assign=args.assign, block=args.rr_block)
+        dots, recs = chunk(frames)
         barrier()
         dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max_over_ranks(dt)
     if rank == 0:
-        # the stream has period 16: pair j and pair j + 16 are the same images, and (away from the clip's ends, where the
+        # (a) the stream has period 16: pair j and pair j + 16 are the same images, and (away from the clip's ends, where the
         # smoothing window is clipped) have the same centre -> the same scalar, whichever rank computed them
-        ok = all(tuple(recs[j]) == tuple(recs[j + 16]) for j in range(n_pairs - 16)) and \
+        period_ok = all(tuple(recs[j]) == tuple(recs[j + 16]) for j in range(n_pairs - 16)) and \
             all(dots[j] == dots[j + 16] for j in range(6, n_pairs - 22))
+        # (b) correctness, not only determinism: the clip's first pairs are the first pairs of the seed-1 stream the oracle
+        # golden of the default workload was made from (a frame depends on t only): records (x, y, cut) of pairs 0..31 and
+        # the scalars of pairs 0..25 (whose +-6 window lies inside both the golden's 32-pair batch and this clip)
+        gold = _golden_check().load_golden(W, H, 32, 1)
+        ok, detail = None, "no oracle golden for this frame size: only the period-16 property across ranks was checked"
+        if not period_ok:
+            ok, detail = False, "pairs 16 apart (same images) gave different records / scalars on different ranks"
+        elif gold is not None:
+            import zlib
+            if zlib.crc32(np.ascontiguousarray(sine_translate_frames(33, W, H, seed=1)).tobytes()) != gold["frames_crc32"]:
+                detail = "synthetic frames differ from the golden's (numpy/libm rounding): only the period-16 property was checked"
+            else:
+                m = min(n_pairs, 32)
+                bad = [j for j in range(m) if (int(recs[j][0]), int(recs[j][1]), bool(recs[j][2])) !=
+                       (gold["x"][j], gold["y"][j], gold["cut"][j])]
+                g = np.asarray(gold["dots"], np.float64)
+                md = min(n_pairs - 6, 26) if n_pairs >= 32 else 0
+                scale = float(np.mean(np.abs(g)))
+                bad_d = [j for j in range(md) if abs(dots[j] - g[j]) > 1e-4 * max(abs(g[j]), scale)]
+                ok = not bad and not bad_d
+                detail = (f"{m} pass-1 records and {md} scalars equal the oracle golden bench_{W}x{H}_b32_s1.json; period-16 property "
+                          f"holds over all {n_pairs} pairs across ranks" if ok else
+                          f"differs from the oracle golden: records of pairs {bad[:4]}, scalars of pairs {bad_d[:4]}")
         _emit(json.dumps({
             "metric": "1080p frame-pairs/sec" if (W, H) == (1920, 1080) else f"{W}x{H} frame-pairs/sec",
             "mode": "one_clip", "value": n_pairs / dt, "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": 1,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic", "checked": bool(ok),
-            "check_detail": "period-16 property over the gathered records and scalars (same images on different ranks give the same bits)",
+            "dtype": "f32", "data": "synthetic", "checked": ok, "check_detail": detail,
             "config": {"workload": f"ONE {W}x{H} clip of {n_pairs} pairs from host ndarrays (uploads inside the timed region), "
                                    f"pairs dealt {args.assign} in blocks of {args.rr_block} over {world} GPU(s)",
                        "pairs_per_step": B, "parallelism": f"pair-shard x{world} ({args.assign}, block {args.rr_block})",
-                       "compute_lanes": args.lanes or 2, "exchange": "host all-gather (gloo) of 32 B per pair after pass 1, 16 B after pass 2",
+                       "compute_lanes": args.lanes or 2,
+                       "exchange": ("host all-gather (gloo) of the 6 + 6 halo records per rank (32 B each) between the passes, 40 B per pair of results at the end"
+                                    if args.assign == "contiguous" else "host all-gather (gloo) of 32 B per pair after pass 1, 16 B after pass 2"),
                        "kernel_signature": kernel_signature()}}))
 
 
@@ -436,7 +500,6 @@ def _emit(line):
 
 
 def main():
-    _quiet_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -458,7 +521,7 @@ def main():
                     help="minimum tiles x pairs of a level for folding its initial UpdateMatrices into the first blur+solve "
                          "launch (library default 10000; 0: never, 1: always)")
     ap.add_argument("--blur-rows", type=int, default=0, help="tiles a k_blur_solve workgroup walks down (0 = automatic)")
-    ap.add_argument("--blur-min-wgs", type=int, default=0, help="automatic strip length of k_blur_solve: longest strips that still give this many workgroups (library default 4000)")
+    ap.add_argument("--blur-min-wgs", type=int, default=0, help="automatic strip length of k_blur_solve: longest strips that still give this many workgroups (library default 3500)")
     ap.add_argument("--tile-order", type=int, default=-1, help="k_blur_solve / k_update_matrices tile order (ffl_set_option)")
     ap.add_argument("--trace-steps", action="store_true", help="print per-step host wall times to stderr")
     ap.add_argument("--lanes", type=int, default=0, help="compute lanes (co-scheduled batches) per context, default 1")
@@ -480,13 +543,19 @@ def main():
                          "dominant kernel only, the other classes are timed in the separate kernel_classes pass")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # Started from a plain shell (`python bench.py --gpus N ...`, the driver's command): this process becomes the PARENT
+        # that spawns one fresh rank process per GPU (FF:1190-1191: the reference's parent creates its pool) and nothing
+        # else -- no torch import, no HIP call, no CPU baseline here.  Rank 0's one JSON line is relayed to stdout,
+        # everything else goes to stderr, the exit status is the first failing rank's (the others are stopped).
+        from funscript_flow_amd.launch import spawn_ranks
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+
+    _quiet_stdout()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world
 
     W, H, B = args.width, args.height, args.batch
     N = W * H
@@ -509,33 +578,49 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP backend has no CPU fallback")
-    if args.rehearse_gloo:
+    # Which device this rank drives: cuda:LOCAL_RANK when the rank sees the whole node, cuda:0 when a visibility mask
+    # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES per rank) leaves it exactly one device, cuda:0 for every rank of a
+    # --rehearse-gloo run.  That two ranks do not share a card is checked below on the devices' PCI identities.
+    ndev = torch.cuda.device_count()
+    if args.rehearse_gloo or (world > 1 and ndev == 1):
         local_rank = 0
-    if torch.cuda.device_count() <= local_rank:
-        print(f"bench.py: FATAL rank {rank}/{world}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} visible GPU(s); "
+    if ndev <= local_rank:
+        print(f"bench.py: FATAL rank {rank}/{world}: LOCAL_RANK {local_rank} but only {ndev} visible GPU(s); "
               f"one rank per GPU is required (use --rehearse-gloo only for single-GPU rehearsals)", file=sys.stderr, flush=True)
         os._exit(3)
     torch.cuda.set_device(local_rank)
-    host_group = None
+    host_group = dev_group = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import datetime
-        if args.rehearse_gloo:
-            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
-            host_group = dist.group.WORLD
-        else:
+        # The default group is gloo (host): it carries the identity check, the gather of the per-pair scalars and, in a
+        # rehearsal, the barrier / MAX.  Ranks of one launch import torch at different speeds on a fresh box: 600 s.
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=600))
+        host_group = dist.group.WORLD
+        pr = torch.cuda.get_device_properties(local_rank)
+        ident = (f"{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', -1):02x}:{getattr(pr, 'pci_device_id', -1):02x}",
+                 str(getattr(pr, "uuid", "")))
+        idents = [None] * world
+        dist.all_gather_object(idents, ident, group=host_group)
+        if not args.rehearse_gloo:
+            clash = [(a, b) for a in range(world) for b in range(a + 1, world) if idents[a] == idents[b]]
+            if clash:
+                if rank == 0:
+                    print(f"bench.py: FATAL: ranks {clash[0][0]} and {clash[0][1]} drive the same GPU ({idents[clash[0][0]][0]}); "
+                          f"{ndev} device(s) visible to rank 0 -- one rank per GPU is required, no number is reported "
+                          f"(use --rehearse-gloo only for single-GPU rehearsals)", file=sys.stderr, flush=True)
+                os._exit(3)
             # RCCL carries only the contract's barrier / MAX (no data-path collective).  Bring the communicator up NOW, with
             # a real collective on the device, so that a broken RCCL / xGMI setup ends the run with one clear message and a
             # non-zero exit code before anything is timed -- never a silent switch to another backend.
             try:
-                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank),
-                                        timeout=datetime.timedelta(seconds=180))
+                dev_group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=300),
+                                           device_id=torch.device("cuda", local_rank))
                 probe = torch.ones(1, device="cuda") * (rank + 1)
-                dist.all_reduce(probe, op=dist.ReduceOp.SUM)
+                dist.all_reduce(probe, op=dist.ReduceOp.SUM, group=dev_group)
                 torch.cuda.synchronize()
                 if int(probe.item()) != world * (world + 1) // 2:
                     raise RuntimeError(f"all_reduce over {world} ranks returned {probe.item()}")
-                host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=300))
             except Exception as e:  # noqa: BLE001
                 print(f"bench.py: FATAL rank {rank}/{world}: the RCCL ('nccl') process group did not come up on cuda:{local_rank}: "
                       f"{type(e).__name__}: {e}\nbench.py: no number is reported; there is no fallback backend for N > 1 "
@@ -563,13 +648,21 @@ def main():
     def barrier():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            if dev_group is not None:
+                dist.barrier(group=dev_group, device_ids=[local_rank])   # RCCL
+            else:
+                dist.barrier(group=host_group)                           # --rehearse-gloo
         torch.cuda.synchronize()
 
+    def max_over_ranks(v):
+        t = torch.tensor([v], dtype=torch.float64, device="cuda" if dev_group is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=dev_group if dev_group is not None else host_group)
+        return float(t.item())
+
     if args.one_clip:
-        one_clip(args, rank, world, local_rank, host_group, barrier, torch, dist)
+        one_clip(args, rank, world, local_rank, host_group, barrier, max_over_ranks, dist)
         if world > 1:
-            dist.barrier()
+            dist.barrier(group=host_group)
             dist.destroy_process_group()
         return
 
@@ -583,12 +676,11 @@ def main():
     plain = not args.independent and args.zoom == 0.0
     checked, check_detail = verify(runner, frames, W, H, B, seed, ctx) if plain else (None, "non-default clip")
     results = runner.results
+    graphs = ctx.graph_stats()
     ctx.close()
 
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.rehearse_gloo else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = max_over_ranks(dt)
         # host gather of the per-pair scalars (x, y, cut, dot): the path's only exchange, ~40 B/pair
         mine = np.array([[r[0], r[1], int(r[4]), d] for recs, dots, _ in results for r, d in zip(recs, dots)], np.float64)
         gathered = [None] * world if rank == 0 else None
@@ -623,7 +715,11 @@ def main():
             "config": {"workload": f"{W}x{H} synthetic sine-translate frame-pair stream, gray frames resident in HBM",
                        "pairs_per_step": B, "frames_per_step": U, "levels": len(level_sizes), "winsize": 15, "iterations": 3,
                        "poly_n": 5, "parallelism": f"pair-shard x{world}", "compute_lanes": args.lanes or 1,
-                       "kernel_signature": kernel_signature()},
+                       "kernel_signature": kernel_signature(),
+                       # hipGraph bookkeeping of the timed context (ffl_graph_stats): per-kernel HIP events (the roofline's
+                       # clock) force one-by-one launches, so the timed region replays nothing unless --no-events is given;
+                       # a non-zero capture_failures would mean a silently slower path and is reported, never hidden
+                       "graphs": graphs},
             "roofline": roof,
             "kernel_ms_per_step": {k: v[1] / args.steps for k, v in prof.items() if v[0]},
             "whole_path": {"alg_bytes_per_pair": sum(alg.values()) / B,
@@ -671,6 +767,7 @@ def main():
                 _capi.set_option("lanes", 2)
                 sdt, sprof, srun, sfr, slv, sU, sctx = resident_pass(256, 256, SB, 30, 5, local_rank, 1, False)
                 schk = verify(srun, sfr, 256, 256, SB, 1, sctx)
+                sgraphs = sctx.graph_stats()
                 sctx.close()
                 salg = alg_bytes_per_batch(256 * 256, SB, sU, slv)
                 out["small_image"] = {"workload": "256x256 pairs (FF:1057), gray frames resident", "pairs_per_step": SB,
@@ -678,7 +775,7 @@ def main():
                                       "whole_path_GBps": sum(salg.values()) * 30 / sdt / 1e9,
                                       "whole_path_frac": sum(salg.values()) * 30 / sdt / 1e9 / PEAK_GBPS,
                                       "launch": "captured hipGraph replay per batch, 2 compute lanes (no per-kernel events in this pass)",
-                                      "compute_lanes": 2,
+                                      "compute_lanes": 2, "graphs": sgraphs,
                                       "checked": schk[0], "check_detail": schk[1]}
                 _capi.set_option("lanes", 2)
                 out["small_image"]["pcie_inclusive_gray"] = pcie_inclusive(256, 256, SB, local_rank, 1, 8 * SB + 1, False, sfr)
@@ -700,7 +797,7 @@ def main():
             out["cpu_baseline"] = cpu_base
         _emit(json.dumps(out))
     if world > 1:
-        dist.barrier()
+        dist.barrier(group=host_group)
         dist.destroy_process_group()
 
 

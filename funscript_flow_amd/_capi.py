@@ -18,7 +18,7 @@ KERNEL_CLASSES = ["k_gray", "k_pyr_level", "k_polyexp", "k_frontend", "k_update_
 EXPORTS = ["ffl_device_count", "ffl_create", "ffl_destroy", "ffl_last_error", "ffl_upload_frame", "ffl_upload_frames", "ffl_upload_frames_raw", "ffl_host_alloc", "ffl_host_free",
            "ffl_flow_pairs",
            "ffl_pass1_result", "ffl_pass1_results", "ffl_radial", "ffl_download_flow", "ffl_upload_flow", "ffl_submit_pair", "ffl_sync",
-           "ffl_num_levels", "ffl_level_size", "ffl_download_frame", "ffl_debug_pair", "ffl_set_option", "ffl_profile_enable",
+           "ffl_num_levels", "ffl_level_size", "ffl_download_frame", "ffl_debug_pair", "ffl_set_option", "ffl_ctx_set_option", "ffl_ctx_get_option", "ffl_graph_stats", "ffl_profile_enable",
            "ffl_profile_read", "ffl_kernel_name", "ffl_device_mem_info", "ffl_estimate_bytes"]
 
 
@@ -70,6 +70,9 @@ def load():
     L.ffl_kernel_name.argtypes = [C.c_int]
     L.ffl_kernel_name.restype = C.c_char_p
     L.ffl_set_option.argtypes = [C.c_char_p, C.c_int]
+    L.ffl_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int]
+    L.ffl_ctx_get_option.argtypes = [vp, C.c_char_p, ip]
+    L.ffl_graph_stats.argtypes = [vp, ip, ip, ip]
     L.ffl_device_mem_info.argtypes = [C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     L.ffl_estimate_bytes.argtypes = [C.c_int] * 5 + [C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     _lib = L
@@ -77,9 +80,18 @@ def load():
 
 
 def set_option(name, value):
-    """Process-wide tuning knob (ffl_set_option); results do not depend on it."""
+    """Process-wide DEFAULT of a tuning knob (ffl_set_option): contexts created afterwards start from it; live contexts
+    keep their own copy (Context.set_option).  Results do not depend on options."""
     if load().ffl_set_option(name.encode(), int(value)) != FFL_OK:
         raise FFLError(f"ffl_set_option({name!r}, {value}) rejected")
+
+
+def get_option(name):
+    """The process-wide default of a knob (ffl_ctx_get_option with no context)."""
+    v = C.c_int()
+    if load().ffl_ctx_get_option(None, name.encode(), C.byref(v)) != FFL_OK:
+        raise FFLError(f"unknown option {name!r}")
+    return v.value
 
 
 def device_count():
@@ -245,6 +257,21 @@ class Context:
 
     def sync(self):
         self._chk(self.L.ffl_sync(self._h))
+
+    def set_option(self, name, value):
+        """A knob of THIS context only (ffl_ctx_set_option); "lanes" is fixed at creation."""
+        self._chk(self.L.ffl_ctx_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int()
+        self._chk(self.L.ffl_ctx_get_option(self._h, name.encode(), C.byref(v)))
+        return v.value
+
+    def graph_stats(self):
+        """{"captured", "replayed", "capture_failures"} of this context's hipGraph path (ffl_graph_stats)."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._chk(self.L.ffl_graph_stats(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"captured": a.value, "replayed": b.value, "capture_failures": c.value}
 
     # ---- test / measurement hooks --------------------------------------------------------------
     def num_levels(self):

@@ -26,22 +26,22 @@
 #define FFL_RAW_RING 4
 
 static thread_local std::string g_create_error = "";
-static int g_num_lanes = 2;  // compute lanes per context created from now on (ffl_set_option "lanes")
-// Schedule of the frame-only kernels (ffl_set_option "run_ahead", see run_batch).  Measured at 1080p, B = 8
-// (pairs/s with 1 / 2 lanes): 0 serial 3840 / 4063, 2 fork-join 3641 / 4101, 1 run-ahead 3943 / 4159.
-static int g_run_ahead = 0;
-// a level's initial UpdateMatrices runs inside its first blur+solve launch when the level has at least this many
-// 64x16 tiles over the batch (0: never).  The folded launch saves an M write + read but runs its extra phase at 3
-// workgroups per CU: worth it only where the launch is long enough to be bandwidth-bound (1080p, B = 32: level 0
-// 2093 vs 1018 + 1217 us; level 2 157 vs 65 + 68 us; level 3 138 vs 34 + 45 us)
-static int g_fuse_first = 10000;
-static int g_merge_expand = 1;  // serial schedule: all levels' pyramid + PolyExp in three merged launches
-// A batch's ~20 launches are captured once per (lane, batch shape, options) into a hipGraph and replayed: the
-// kernels take only pointers and geometry (per-batch indices live in the lane's device table), so nothing in the
-// graph changes from batch to batch.  Host time per batch drops from one launch call per kernel to one graph
-// launch -- what matters at the reference's 256x256 operating point, where a whole batch is a fraction of a ms.
-static int g_use_graph = 1;
-static int g_opt_epoch = 0;  // bumped by every ffl_set_option: a captured graph is only replayed under the options it was captured with
+// The process-wide option set (ffl_set_option): the defaults of contexts created AFTERWARDS.  Every context copies it at
+// ffl_create (ffl_ctx::opt) and is from then on only changed through ffl_ctx_set_option, which bumps that context's own
+// graph epoch -- two contexts of one process (one per GPU) share no knob and do not invalidate each other's graphs.
+//   run_ahead   schedule of the frame-only kernels (see enqueue_batch).  Measured at 1080p, B = 8 (pairs/s with 1 / 2
+//               lanes): 0 serial 3840 / 4063, 2 fork-join 3641 / 4101, 1 run-ahead 3943 / 4159.
+//   fuse_first  a level's initial UpdateMatrices runs inside its first blur+solve launch when the level has at least this
+//               many 64x16 tiles over the batch (0: never).  The folded launch saves an M write + read but runs its extra
+//               phase at 3 workgroups per CU: worth it only where the launch is long enough to be bandwidth-bound (1080p,
+//               B = 32: level 0 2093 vs 1018 + 1217 us; level 2 157 vs 65 + 68 us; level 3 138 vs 34 + 45 us)
+//   use_graph   a batch's ~20 launches are captured once per (lane, batch shape, option epoch) into a hipGraph and
+//               replayed: the kernels take only pointers and geometry (per-batch indices live in the lane's device table),
+//               so nothing in the graph changes from batch to batch.  Host time per batch drops from one launch call per
+//               kernel to one graph launch -- what matters at the reference's 256x256 operating point, where a whole
+//               batch is a fraction of a ms.
+static FflOptions g_opts;
+static std::mutex g_opt_mu;
 
 struct ProfRec {
     int cls;
@@ -101,7 +101,7 @@ struct CopyPool {
     void copy(uint8_t *dst, ptrdiff_t dst_pitch, const uint8_t *src, ptrdiff_t src_pitch, size_t row_bytes, int rows, int threads) {
         const int parts = (row_bytes * (size_t)rows < (size_t)(1 << 20) || threads < 2) ? 1 : (threads < rows ? threads : rows);
         if (parts > 1 && (int)workers.size() < parts - 1) {
-            // (re)size once; helpers are idle here because copy() is only called under the context lock
+            // (re)size once; helpers are idle here because copy() is only called under the context's upload lock (up_mu)
             shutdown();
             stop = false;
             start(parts - 1);
@@ -137,10 +137,12 @@ struct CopyPool {
         workers.clear();
     }
 };
-static int g_copy_threads = 4;  // host threads sharing a staging copy (ffl_set_option "copy_threads", 1 = caller only)
 
 struct ffl_ctx {
     int device = 0, w = 0, h = 0, levels = 0;
+    FflOptions opt;      // this context's own option set (copied from the process-wide defaults at ffl_create)
+    int opt_epoch = 0;   // bumped by every applied ffl_ctx_set_option: a graph is only replayed under the options it was captured with
+    int graph_captured = 0, graph_replayed = 0, graph_failed = 0;  // ffl_graph_stats
     CopyPool pool;
     int n_fslots = 0, n_slots = 0, max_batch = 0;
     size_t N = 0;
@@ -229,17 +231,25 @@ struct ffl_ctx {
     int prof_launches[FFL_K_COUNT] = {0};
     double prof_ms[FFL_K_COUNT] = {0};
     std::string err;
-    // Every entry point takes this lock, so calls from several host threads are safe.  NO call holds it while it waits
-    // for the device or copies frames: ffl_pass1_result, ffl_download_flow, ffl_radial, ffl_upload_flow, ffl_sync and
-    // ffl_host_free drop it around their waits, ffl_upload_frames(_raw) around the staging memcpy -- so a thread
-    // collecting results does not hold up another one that is uploading frames or queueing the next batch (SURVEY 8b:
-    // submit / pass1 / radial on distinct slots may come from different host threads).
-    // Two small locks order the users of shared single-copy resources among themselves; both are taken BEFORE `mu`:
+    // Every entry point takes this lock, so calls from several host threads are safe.  The calls a pipeline makes per
+    // batch do not hold it while they wait for the device or copy frames: ffl_pass1_result, ffl_download_flow, ffl_radial,
+    // ffl_upload_flow, ffl_sync and ffl_host_free drop it around their waits, ffl_upload_frames(_raw) around the staging
+    // memcpy -- so a thread collecting results does not hold up another one that is uploading frames or queueing the next
+    // batch (submit / pass1 / radial on distinct slots may come from different host threads).  Exceptions, all
+    // rare or measurement-only: ffl_flow_pairs waits under the lock when a lane has FFL_EV_RING batches queued (its table
+    // ring is full) or evicts a captured graph (the 17th batch shape of a lane); ffl_debug_pair and ffl_download_frame
+    // are test hooks and wait under it; ffl_profile_read collects its timing events under it.
+    // A wait that runs WITHOUT the lock only ever waits on EVENTS, never on a lane's stream: another thread may be inside
+    // hipStreamBeginCapture / EndCapture on that stream (a new batch shape), and synchronising a capturing stream is an
+    // error that also invalidates the capture; hipEventSynchronize on an event recorded outside the capture is legal.
+    // Two small locks order the users of shared single-copy resources among themselves; both are taken BEFORE `mu`, and
+    // up_mu before post_mu where a call needs both (ffl_sync):
     //   up_mu    uploaders: the per-slot staging areas, the copy pool and the raw-frame ring
     //   post_mu  users of stream `post` and its single pinned tables / result buffer (ffl_radial, ffl_upload_flow)
     mutable std::recursive_mutex mu;
     std::mutex up_mu, post_mu;
     int graph_bad_epoch = -1;  // option epoch in which a graph capture failed: batches launch eagerly until it changes
+    bool graph_fail_reported = false;
 };
 typedef std::unique_lock<std::recursive_mutex> CtxLock;
 
@@ -525,6 +535,11 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     c->n_fslots = n_frame_slots;
     c->n_slots = n_flow_slots;
     c->max_batch = max_batch;
+    {
+        std::lock_guard<std::mutex> g(g_opt_mu);
+        c->opt = g_opts;
+    }
+    const int num_lanes = c->opt.lanes;  // fixed for the life of the context
     level_geometry(c);
     polyexp_prepare(&c->pc);
 #define CCHK(call)                                                                                       \
@@ -551,7 +566,7 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     CCHK(hipHostMalloc(&c->h_stage_gray, (size_t)n_frame_slots * N, hipHostMallocDefault));
     CCHK(hipHostMalloc(&c->h_stage_bgr, (size_t)n_frame_slots * N * 3, hipHostMallocDefault));
     c->p1_blocks = ffl_pass1_blocks(width, height);
-    c->lanes.resize(g_num_lanes);
+    c->lanes.resize(num_lanes);
     for (auto &L : c->lanes) {
         CCHK(hipStreamCreateWithFlags(&L.st, hipStreamNonBlocking));
         // st_aux (run-ahead / fork-join schedules only) are created on first use: HIP multiplexes streams
@@ -602,7 +617,7 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     CCHK(hipHostMalloc(&c->h_radial, sizeof(double) * FFL_MAXB, hipHostMallocMapped));
     CCHK(hipHostGetDevicePointer((void **)&c->d_radial, c->h_radial, 0));
     c->ev_uploaded.assign(n_frame_slots, nullptr);
-    c->ev_last_use.assign((size_t)n_frame_slots * g_num_lanes, nullptr);  // handles into the lanes' rings
+    c->ev_last_use.assign((size_t)n_frame_slots * num_lanes, nullptr);  // handles into the lanes' rings
     c->frame_valid.assign(n_frame_slots, 0);
     for (auto &e : c->up_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : c->post_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -646,8 +661,13 @@ int ffl_estimate_bytes(int width, int height, int n_frame_slots, int n_flow_slot
     }
     lane += sizeof(float) * N * max_batch * (5 + 5 + 2 + 2);                                            // M x 2, flow A / B
     lane += (size_t)ffl_pass1_blocks(width, height) * max_batch * 16;
-    size_t dev = (size_t)g_num_lanes * lane + (size_t)n_frame_slots * N * 4 + sizeof(float) * 2 * N * n_flow_slots + ((size_t)1 << 20);
-    size_t pin = (size_t)n_frame_slots * N * 4 + sizeof(Pass1Result) * n_flow_slots + (size_t)g_num_lanes * sizeof(BatchTab) * FFL_EV_RING + ((size_t)1 << 20);
+    int num_lanes;
+    {
+        std::lock_guard<std::mutex> gl(g_opt_mu);
+        num_lanes = g_opts.lanes;
+    }
+    size_t dev = (size_t)num_lanes * lane + (size_t)n_frame_slots * N * 4 + sizeof(float) * 2 * N * n_flow_slots + ((size_t)1 << 20);
+    size_t pin = (size_t)n_frame_slots * N * 4 + sizeof(Pass1Result) * n_flow_slots + (size_t)num_lanes * sizeof(BatchTab) * FFL_EV_RING + ((size_t)1 << 20);
     if (device_bytes) *device_bytes = dev;
     if (pinned_bytes) *pinned_bytes = pin;
     return FFL_OK;
@@ -725,16 +745,18 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
     // frames that sit back to back in one ffl_host_alloc buffer go to the device straight out of it
     bool direct = (size_t)stride_bytes == row && in_host_buf(c, frames[0], fbytes * n);
     for (int i = 1; direct && i < n; i++) direct = frames[i] == frames[0] + (size_t)i * fbytes;
-    // the device copies of these slots may still be read by batches queued on any lane
-    for (int i = 0; i < n; i++)
-        for (size_t l = 0; l < c->lanes.size(); l++) {
-            hipEvent_t e = c->ev_last_use[(size_t)(first + i) * c->lanes.size() + l];
-            if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
-        }
     // Staged frames go to the device in pieces of >= 8 MiB as soon as they are in pinned memory, so the transfer of
     // the first frames runs while the host still copies the later ones (one 200 MB transfer issued after a 33-frame
     // BGR run had been staged left the device waiting for it); small frames still travel as one run.
-    auto send = [&](int i0, int i1) -> int {  // frames i0 .. i1-1 of the run
+    auto send = [&](int i0, int i1) -> int {  // frames i0 .. i1-1 of the run; called with the context lock held
+        // the device copies of these slots may still be read by batches queued on any lane -- looked up HERE, right before
+        // the transfer is queued: the lock was dropped for the staging copies, and a batch another thread queued meanwhile
+        // must be ordered ahead of the transfer that overwrites its frame
+        for (int i = i0; i < i1; i++)
+            for (size_t l = 0; l < c->lanes.size(); l++) {
+                hipEvent_t e = c->ev_last_use[(size_t)(first + i) * c->lanes.size() + l];
+                if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
+            }
         uint8_t *gray = c->d_gray + (size_t)(first + i0) * N;
         const uint8_t *src = (direct ? frames[0] : stage0) + (size_t)i0 * fbytes;
         const int m = i1 - i0;
@@ -759,6 +781,7 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
     } else {
         int sent = 0;
         size_t pending = 0;
+        const int copy_threads = c->opt.copy_threads;
         for (int i = 0; i < n; i++) {
             const int fs = first + i;
             // the previous transfer out of this slot's staging area must have left the host buffer; the wait and the
@@ -767,7 +790,7 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
             lk.unlock();
             hipError_t pe = prev ? hipEventSynchronize(prev) : hipSuccess;
             if (pe == hipSuccess)
-                c->pool.copy(stage0 + (size_t)i * fbytes, (ptrdiff_t)row, frames[i], stride_bytes, row, height, g_copy_threads);
+                c->pool.copy(stage0 + (size_t)i * fbytes, (ptrdiff_t)row, frames[i], stride_bytes, row, height, copy_threads);
             lk.lock();
             HIPCHK(c, pe);
             pending += fbytes;
@@ -842,8 +865,9 @@ int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *fr
         // a tightly packed frame in ffl_host_alloc memory goes to the device straight out of it
         const bool direct = (size_t)stride_bytes == fp.stride && in_host_buf(c, data, fbytes);
         if (!direct) {
+            const int copy_threads = c->opt.copy_threads;
             lk.unlock();  // the staging copy runs without the context lock (up_mu protects the ring and the pool)
-            c->pool.copy(rb.h, (ptrdiff_t)fp.stride, data, stride_bytes, fp.stride, sh, g_copy_threads);
+            c->pool.copy(rb.h, (ptrdiff_t)fp.stride, data, stride_bytes, fp.stride, sh, copy_threads);
             lk.lock();
         }
         for (size_t l = 0; l < c->lanes.size(); l++) {  // batches still reading the slot's previous frame
@@ -920,7 +944,7 @@ static int enqueue_batch(ffl_ctx *c, ffl_ctx::Lane &L, const BatchTab &T, int n,
     //      starts only after all of them -- it is never co-scheduled with anything
     //   1  run-ahead: one side stream, the chain waits per level, so coarse-level flow kernels overlap
     //      the finer levels' expansion (fastest with one lane, but stretches those launches)
-    const int mode = cap ? 0 : g_run_ahead;
+    const int mode = cap ? 0 : c->opt.run_ahead;
     if (mode) {
         for (int k = 0; k < (mode == 2 ? 4 : 1); k++)
             if (!L.st_aux[k]) HIPCHK(c, hipStreamCreateWithFlags(&L.st_aux[k], hipStreamNonBlocking));
@@ -936,7 +960,7 @@ static int enqueue_batch(ffl_ctx *c, ffl_ctx::Lane &L, const BatchTab &T, int n,
     }
     const bool run_ahead = mode == 1;
     bool expanded = mode != 0;
-    if (mode == 0 && g_merge_expand && c->levels + 1 <= FFL_MAX_JOBS) {
+    if (mode == 0 && c->opt.merge_expand && c->levels + 1 <= FFL_MAX_JOBS) {
         // serial schedule, merged form: the frame-only work of ALL levels up front in three launches
         // (pyramid phase A + B, PolyExp) instead of ten small ones whose ramps and tails leave the device idle
         PyrJob pj[FFL_MAX_JOBS];
@@ -964,7 +988,7 @@ static int enqueue_batch(ffl_ctx *c, ffl_ctx::Lane &L, const BatchTab &T, int n,
         }
         {
             ProfScope ps(c, FFL_K_PYRAMID, st);
-            if (!ffl_launch_pyr_multi(c->d_gray, N, ut, nU, c->w, c->h, pj, nj, st))
+            if (!ffl_launch_pyr_multi(c->d_gray, N, ut, nU, c->w, c->h, pj, nj, c->opt, st))
                 for (int k = c->levels; k >= 0; k--) {  // a level outside the merged kinds: per-level kernels
                     const LevelGeom &g = c->geom[k];
                     ffl_launch_pyr_level(c->d_gray, N, ut, nU, c->w, c->h, g.lw, g.lh, g.gk, L.d_T + L.t_off[k],
@@ -994,11 +1018,11 @@ static int enqueue_batch(ffl_ctx *c, ffl_ctx::Lane &L, const BatchTab &T, int n,
         int mi = 0;
         // fuse_first: the level's initial UpdateMatrices (and flow upsample) run inside the first blur+solve
         // launch; the debug capture wants the initial flow and M in memory, so it keeps the separate launch
-        const bool fuse_first = g_fuse_first > 0 && !cap && (long)((lw + 63) / 64) * ((lh + 15) / 16) * n >= g_fuse_first;
+        const bool fuse_first = c->opt.fuse_first > 0 && !cap && (long)((lw + 63) / 64) * ((lh + 15) / 16) * n >= c->opt.fuse_first;
         if (!fuse_first) {
             ProfScope ps(c, FFL_K_UPDATE_MATRICES, st);
             // the x2 upsample of the coarser level's flow (K3) is fused into this launch
-            ffl_launch_update_matrices(Rk, R_stride, plane, pt, k, n, L.d_M[mi], M_stride, lw, lh, pw, ph, pw == 0, cap != nullptr, st);
+            ffl_launch_update_matrices(Rk, R_stride, plane, pt, k, n, L.d_M[mi], M_stride, lw, lh, pw, ph, pw == 0, cap != nullptr, c->opt, st);
         }
         bool captured = false;
         auto capture = [&]() -> int {
@@ -1021,10 +1045,10 @@ static int enqueue_batch(ffl_ctx *c, ffl_ctx::Lane &L, const BatchTab &T, int n,
             {
                 ProfScope ps(c, FFL_K_BLUR_SOLVE, st, it > 0 && !cap);  // the three iterations are queued back to back
                 if (it == 0 && fuse_first)
-                    ffl_launch_blur_solve_first(L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, k, n, lw, lh, pw, ph, st);
+                    ffl_launch_blur_solve_first(L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, k, n, lw, lh, pw, ph, c->opt, st);
                 else
                     ffl_launch_blur_solve(L.d_M[mi], L.d_M[mi ^ 1], M_stride, Rk, R_stride, plane, pt, k, n, lw, lh,
-                                          update, cap != nullptr, st);
+                                          update, cap != nullptr, c->opt, st);
             }
             if (update) mi ^= 1;
         }
@@ -1082,19 +1106,22 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     HIPCHK(c, hipMemcpyAsync(L.d_tab, &T, sizeof(BatchTab), hipMemcpyHostToDevice, st));
     L.tab_used[e] = true;
 
-    const bool use_graph = g_use_graph && !cap && c->prof_mask == 0 && g_run_ahead == 0;
+    const bool use_graph = c->opt.use_graph && !cap && c->prof_mask == 0 && c->opt.run_ahead == 0;
     if (use_graph) {
         ffl_ctx::Lane::GraphEntry *ge = nullptr;
         for (auto &g : L.graphs)
-            if (g.n == n && g.nU == nU && g.pov == pov_mode && g.epoch == g_opt_epoch) ge = &g;
-        if (!ge && c->graph_bad_epoch != g_opt_epoch) {
-            ffl_ctx::Lane::GraphEntry g = {n, nU, pov_mode, g_opt_epoch, nullptr, nullptr};
-            bool ok = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (g.n == n && g.nU == nU && g.pov == pov_mode && g.epoch == c->opt_epoch) ge = &g;
+        if (!ge && c->graph_bad_epoch != c->opt_epoch) {
+            ffl_ctx::Lane::GraphEntry g = {n, nU, pov_mode, c->opt_epoch, nullptr, nullptr};
+            hipError_t fail = hipSuccess;
+            fail = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            bool ok = fail == hipSuccess;
             if (ok) {
                 const int rc = enqueue_batch(c, L, T, n, nU, pov_mode, nullptr);
-                const hipError_t ce = hipStreamEndCapture(st, &g.graph);  // always: the stream must leave capture mode
-                ok = rc == FFL_OK && ce == hipSuccess && g.graph &&
-                     hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0) == hipSuccess;
+                fail = hipStreamEndCapture(st, &g.graph);  // always: the stream must leave capture mode
+                if (fail == hipSuccess && (rc != FFL_OK || !g.graph)) fail = hipErrorStreamCaptureInvalidated;
+                if (fail == hipSuccess) fail = hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0);
+                ok = fail == hipSuccess;
             }
             if (ok) {
                 if (L.graphs.size() >= 16) {  // bounded cache: callers that vary the batch shape a lot re-capture
@@ -1106,17 +1133,26 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
                 }
                 L.graphs.push_back(g);
                 ge = &L.graphs.back();
+                c->graph_captured++;
             } else {
                 // nothing of the failed capture is kept (it would leak once per batch), the sticky error is cleared, and
                 // this context launches eagerly until the option set changes -- the batch itself is not lost
                 if (g.exec) hipGraphExecDestroy(g.exec);
                 if (g.graph) hipGraphDestroy(g.graph);
                 (void)hipGetLastError();
-                c->graph_bad_epoch = g_opt_epoch;
+                c->graph_bad_epoch = c->opt_epoch;
+                // never silent: counted (ffl_graph_stats, bench.py `config.graphs`) and said once per context on stderr
+                c->graph_failed++;
+                if (!c->graph_fail_reported) {
+                    c->graph_fail_reported = true;
+                    fprintf(stderr, "libffl_hip: hipGraph capture of a %d-pair batch failed (%s); this context launches its batches "
+                                    "one kernel at a time until its options change (results are unaffected)\n", n, hipGetErrorString(fail));
+                }
             }
         }
         if (ge) {
             HIPCHK(c, hipGraphLaunch(ge->exec, st));
+            c->graph_replayed++;
         } else {
             int rc = enqueue_batch(c, L, T, n, nU, pov_mode, nullptr);
             if (rc) return rc;
@@ -1336,86 +1372,139 @@ int ffl_submit_pair(ffl_ctx *c, int slot, const uint8_t *prev, const uint8_t *ne
 
 int ffl_sync(ffl_ctx *c) {
     if (!c) return FFL_ERR_INVALID;
+    // up_mu / post_mu: an upload or pass-2 call of another thread that is under way finishes queueing first, so the latest
+    // events of streams `copy` and `post` stand for everything those calls put there
+    std::unique_lock<std::mutex> ul(c->up_mu);
+    std::unique_lock<std::mutex> pl(c->post_mu);
     CtxLock lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    std::vector<hipStream_t> sts;  // the streams live as long as the context: wait for them without the lock
-    sts.push_back(c->s_copy);
-    for (auto &L : c->lanes) sts.push_back(L.st);
-    sts.push_back(c->s_post);
+    // Wait on EVENTS, never on the lane streams: without the lock another thread may be capturing a new batch shape on a
+    // lane's stream, and hipStreamSynchronize on a capturing stream fails and invalidates the capture.  Each handle is a
+    // ring entry that is only ever re-recorded for LATER work of its stream, so waiting on it stays sufficient.
+    std::vector<hipEvent_t> evs;
+    if (c->up_next) evs.push_back(c->up_ring[(c->up_next - 1) % (2 * FFL_EV_RING)]);
+    for (auto &rb : c->raw)
+        if (rb.busy && rb.ev) evs.push_back(rb.ev);
+    for (auto &L : c->lanes)
+        if (L.ev_done) evs.push_back(L.ev_done);
+    if (c->post_next) evs.push_back(c->post_ring[(c->post_next - 1) % FFL_EV_RING]);
     lk.unlock();
     hipError_t e = hipSuccess;
-    for (auto s : sts)
-        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    for (auto ev : evs)
+        if (e == hipSuccess) e = hipEventSynchronize(ev);
     lk.lock();
     HIPCHK(c, e);
     return FFL_OK;
 }
 
-static int set_option_impl(const char *name, int value) {
+// one knob of an option set; `live`: the set belongs to an existing context (its lane count is fixed)
+static int set_option_impl(FflOptions &o, const char *name, int value, bool live) {
     if (!strcmp(name, "blur_tile_h")) {  // fixed: the box-sum order is anchored to blocks of 16 rows
         return value == 16 ? FFL_OK : FFL_ERR_INVALID;
     }
     if (!strcmp(name, "fuse_first")) {  // minimum tiles x pairs of a level for the folded first launch; 0: never
         if (value < 0) return FFL_ERR_INVALID;
-        g_fuse_first = value;
+        o.fuse_first = value;
         return FFL_OK;
     }
     if (!strcmp(name, "merge_expand")) {  // 1 (default): merged frame-expansion launches, 0: one set per level
-        g_merge_expand = value != 0;
+        o.merge_expand = value != 0;
         return FFL_OK;
     }
     if (!strcmp(name, "blur_rows")) {  // tiles a k_blur_solve workgroup walks down: 0 automatic, 1..64
         if (value < 0 || value > 64) return FFL_ERR_INVALID;
-        ffl_set_blur_rows(value);
+        o.blur_rows = value;
         return FFL_OK;
     }
     if (!strcmp(name, "blur_min_wgs")) {  // automatic strip length: the longest strips that still give this many workgroups
         if (value < 1) return FFL_ERR_INVALID;
-        ffl_set_blur_min_wgs(value);
+        o.blur_min_wgs = value;
         return FFL_OK;
     }
     if (!strcmp(name, "tile_order")) {  // 0 pair-major, 1 tile-major (ffl_tile_coord)
         if (value < 0 || value > 1) return FFL_ERR_INVALID;
-        ffl_set_tile_order(value);
+        o.tile_order = value;
         return FFL_OK;
     }
     if (!strcmp(name, "pyr_coarse")) {  // 1 (default): one-pass kernel for the two coarse pyramid levels, 0: H + V kernel pairs
-        ffl_set_pyr_coarse(value != 0);
+        o.pyr_coarse = value != 0;
         return FFL_OK;
     }
     if (!strcmp(name, "copy_threads")) {  // host threads sharing a staging copy of >= 1 MiB (1 = the caller alone)
         if (value < 1 || value > 16) return FFL_ERR_INVALID;
-        g_copy_threads = value;
+        o.copy_threads = value;
         return FFL_OK;
     }
     if (!strcmp(name, "graph")) {  // 1 (default): replay a batch's launches from a captured hipGraph, 0: launch eagerly
-        g_use_graph = value != 0;
+        o.use_graph = value != 0;
         return FFL_OK;
     }
-    if (!strcmp(name, "lanes")) {  // compute lanes of contexts created afterwards
+    if (!strcmp(name, "lanes")) {  // compute lanes: a property of the context's buffers, fixed at ffl_create
         if (value < 1 || value > 4) return FFL_ERR_INVALID;
-        g_num_lanes = value;
+        if (live) return value == o.lanes ? FFL_OK : FFL_ERR_STATE;
+        o.lanes = value;
         return FFL_OK;
     }
     if (!strcmp(name, "run_ahead")) {  // frame-only expansion schedule: 0 serial, 1 run-ahead, 2 fork/join
         if (value < 0 || value > 2) return FFL_ERR_INVALID;
-        g_run_ahead = value;
+        o.run_ahead = value;
         return FFL_OK;
     }
     return FFL_ERR_INVALID;
 }
 
+static int get_option_impl(const FflOptions &o, const char *name, int *value) {
+    struct { const char *n; int v; } tab[] = {
+        {"blur_tile_h", 16}, {"fuse_first", o.fuse_first}, {"merge_expand", o.merge_expand}, {"blur_rows", o.blur_rows},
+        {"blur_min_wgs", o.blur_min_wgs}, {"tile_order", o.tile_order}, {"pyr_coarse", o.pyr_coarse},
+        {"copy_threads", o.copy_threads}, {"graph", o.use_graph}, {"lanes", o.lanes}, {"run_ahead", o.run_ahead}};
+    for (auto &t : tab)
+        if (!strcmp(name, t.n)) {
+            *value = t.v;
+            return FFL_OK;
+        }
+    return FFL_ERR_INVALID;
+}
+
 int ffl_set_option(const char *name, int value) {
     if (!name) return FFL_ERR_INVALID;
-    const int rc = set_option_impl(name, value);
-    if (rc == FFL_OK) g_opt_epoch++;  // only an option that was actually applied invalidates the captured graphs
+    std::lock_guard<std::mutex> g(g_opt_mu);
+    return set_option_impl(g_opts, name, value, false);
+}
+
+int ffl_ctx_set_option(ffl_ctx *c, const char *name, int value) {
+    if (!c || !name) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
+    const int rc = set_option_impl(c->opt, name, value, true);
+    if (rc == FFL_OK) c->opt_epoch++;  // only an option that was actually applied invalidates this context's captured graphs
+    else if (rc == FFL_ERR_STATE) set_err(c, rc, "ffl_ctx_set_option: \"lanes\" is fixed once the context exists (%d)", c->opt.lanes);
+    else set_err(c, rc, "ffl_ctx_set_option: unknown option or value out of range: %s = %d", name, value);
     return rc;
+}
+
+int ffl_ctx_get_option(ffl_ctx *c, const char *name, int *value) {
+    if (!name || !value) return FFL_ERR_INVALID;
+    if (!c) {
+        std::lock_guard<std::mutex> g(g_opt_mu);
+        return get_option_impl(g_opts, name, value);
+    }
+    CtxLock lk(c->mu);
+    return get_option_impl(c->opt, name, value);
+}
+
+int ffl_graph_stats(ffl_ctx *c, int *captured, int *replayed, int *capture_failures) {
+    if (!c) return FFL_ERR_INVALID;
+    CtxLock lk(c->mu);
+    if (captured) *captured = c->graph_captured;
+    if (replayed) *replayed = c->graph_replayed;
+    if (capture_failures) *capture_failures = c->graph_failed;
+    return FFL_OK;
 }
 
 int ffl_profile_enable(ffl_ctx *c, unsigned class_mask) {
     if (!c) return FFL_ERR_INVALID;
+    ffl_sync(c);  // before the context lock: ffl_sync takes up_mu / post_mu first (lock order)
     CtxLock lk(c->mu);
-    ffl_sync(c);
     prof_collect(c);
     c->prof_mask = class_mask;
     return FFL_OK;
@@ -1423,10 +1512,10 @@ int ffl_profile_enable(ffl_ctx *c, unsigned class_mask) {
 
 int ffl_profile_read(ffl_ctx *c, int k, int *launches, double *total_ms) {
     if (!c || k < 0 || k >= FFL_K_COUNT) return FFL_ERR_INVALID;
-    CtxLock lk(c->mu);
-    int rc = ffl_sync(c);
+    int rc = ffl_sync(c);  // before the context lock (lock order up_mu -> post_mu -> mu)
     if (rc) return rc;
-    prof_collect(c);
+    CtxLock lk(c->mu);
+    prof_collect(c);  // launches another thread queued since the sync are waited for here, under the lock (measurement hook)
     if (launches) *launches = c->prof_launches[k];
     if (total_ms) *total_ms = c->prof_ms[k];
     c->prof_launches[k] = 0;

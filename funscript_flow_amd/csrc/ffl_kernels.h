@@ -94,10 +94,26 @@ struct PolyJobs {
     int n;
 };
 
+// Tuning knobs (ffl_set_option / ffl_ctx_set_option; results never depend on them).  The process-wide set holds the
+// defaults of contexts created afterwards; every context keeps its OWN copy, taken at ffl_create, so two contexts of one
+// process (one per GPU, or several on one device) neither share a knob nor invalidate each other's captured graphs.
+struct FflOptions {
+    int lanes = 2;          // compute lanes (co-scheduled batches) -- fixed once the context exists
+    int run_ahead = 0;      // schedule of the frame-only kernels: 0 serial, 1 run-ahead, 2 fork/join
+    int fuse_first = 10000; // minimum tiles x pairs of a level for the folded first blur+solve launch (0: never)
+    int merge_expand = 1;   // pyramid + PolyExp of all levels in three merged launches
+    int use_graph = 1;      // replay a batch's launches from a captured hipGraph
+    int copy_threads = 4;   // host threads sharing a staging copy
+    int blur_rows = 0;      // tiles a k_blur_solve workgroup walks down (0: automatic)
+    int blur_min_wgs = 3500; // automatic strip length: the longest strips that still give this many workgroups
+    int tile_order = 0;     // 0 pair-major, 1 tile-major (ffl_tile_coord)
+    int pyr_coarse = 1;     // one-pass kernel for the x1/4 and x1/8 pyramid levels where sizes allow
+};
+
 // ---- launchers (each enqueues on `st` and returns; no synchronisation) ----------------------
 // all pyramid levels in two launches; false (nothing launched) when a level needs the generic kernels
 bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, const UTab *ut, int nU, int w, int h, const PyrJob *levels,
-                          int n, hipStream_t st);
+                          int n, const FflOptions &opt, hipStream_t st);
 void ffl_launch_polyexp_multi(const PolyJob *levels, int n, int nU, PolyConsts pc, hipStream_t st);
 void ffl_launch_frontend(const uint8_t *src, uint8_t *gray, FrontParams p, hipStream_t st);
 void ffl_launch_gray(const uint8_t *bgr, uint8_t *gray, int n_pixels, hipStream_t st);
@@ -111,20 +127,17 @@ void ffl_launch_polyexp(const float *I, size_t I_stride, float *R, size_t R_stri
 // pw == 0: the flow is read from pt.flow, or taken as zero without touching memory when zero_flow != 0
 void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, const PairTab *pt, int level, int nB, float *M,
                                 size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, int store_flow,
-                                hipStream_t st);
+                                const FflOptions &opt, hipStream_t st);
 // update != 0: the next UpdateMatrices is fused in; the solved flow then only reaches memory when store_flow != 0
 // (it is dead until the level's last iteration, which always stores it)
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
                            size_t plane, const PairTab *pt, int level, int nB, int lw, int lh, int update, int store_flow,
-                           hipStream_t st);
+                           const FflOptions &opt, hipStream_t st);
 
 
 void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane,
-                                 const PairTab *pt, int level, int nB, int lw, int lh, int pw, int ph, hipStream_t st);
-void ffl_set_blur_rows(int n);  // tiles a k_blur_solve workgroup walks down (0 = automatic)
-void ffl_set_blur_min_wgs(int n);  // automatic strip length: the longest strips that still give this many workgroups
-void ffl_set_pyr_coarse(int on);    // 1 (default): one-pass kernel for the x1/4 and x1/8 pyramid levels where sizes allow
-void ffl_set_tile_order(int order);  // 0 pair-major, 1 tile-major (see ffl_tile_coord)
+                                 const PairTab *pt, int level, int nB, int lw, int lh, int pw, int ph, const FflOptions &opt,
+                                 hipStream_t st);
 
 int ffl_pass1_blocks(int w, int h);
 // pass 1 of the level-0 flows pt->flow[0][b]; records go to pt->res[b]

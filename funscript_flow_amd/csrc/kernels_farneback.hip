@@ -715,12 +715,9 @@ static int ffl_pyr_kind(int w, int h, int lw, int lh, int ksize) {
     return -1;
 }
 
-static int g_pyr_coarse = 1;
-void ffl_set_pyr_coarse(int on) { g_pyr_coarse = on; }
-
 // (running the coarse kernel on a side stream beside the fine levels was tried: 5595 vs 5606 pairs/s, not kept)
 bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, const UTab *__restrict__ ut, int nU, int w, int h, const PyrJob *lv,
-                          int n, hipStream_t st) {
+                          int n, const FflOptions &opt, hipStream_t st) {
     if (n > FFL_MAX_JOBS) return false;
     PyrJobs A = {}, B = {};
     unsigned ta = 0, tb = 0;
@@ -728,7 +725,7 @@ bool ffl_launch_pyr_multi(const uint8_t *gray_base, size_t gray_stride, const UT
         if (ffl_pyr_kind(w, h, lv[i].lw, lv[i].lh, lv[i].gk.ksize) < 0) return false;
     // the x1/8 and x1/4 levels (radius 9 and 4) in one pass over the frame where the sizes allow it
     int skip0 = -1, skip1 = -1;
-    if (g_pyr_coarse)
+    if (opt.pyr_coarse)
         for (int i = 0; i + 1 < n; i++)
             if (lv[i].gk.ksize == 19 && lv[i + 1].gk.ksize == 9 &&
                 ffl_launch_pyr_coarse(gray_base, gray_stride, ut, nU, w, h, lv[i + 1], lv[i], st)) {
@@ -1149,23 +1146,20 @@ __global__ __launch_bounds__(256) void k_update_matrices(const float *__restrict
     }
 }
 
-static int g_tile_order = 0;
-void ffl_set_tile_order(int order) { g_tile_order = order; }
-
 void ffl_launch_update_matrices(const float *R, size_t R_stride, size_t plane, const PairTab *pt, int level, int nB,
                                 float *M,
                                 size_t M_stride, int lw, int lh, int pw, int ph, int zero_flow, int store_flow,
-                                hipStream_t st) {
+                                const FflOptions &opt, hipStream_t st) {
     dim3 grid(ffl_tile_grid((lw + 63) / 64, (lh + 15) / 16, nB));
     if (pw > 0)
         hipLaunchKernelGGL(k_update_matrices<1>, grid, dim3(256), 0, st, R, R_stride, plane, pt, level, M, M_stride, lw, lh,
-                           pw, ph, (double)pw / lw, (double)ph / lh, store_flow, nB, g_tile_order);
+                           pw, ph, (double)pw / lw, (double)ph / lh, store_flow, nB, opt.tile_order);
     else if (zero_flow)
         hipLaunchKernelGGL(k_update_matrices<2>, grid, dim3(256), 0, st, R, R_stride, plane, pt, level, M, M_stride, lw, lh, 0, 0,
-                           1.0, 1.0, 0, nB, g_tile_order);
+                           1.0, 1.0, 0, nB, opt.tile_order);
     else
         hipLaunchKernelGGL(k_update_matrices<0>, grid, dim3(256), 0, st, R, R_stride, plane, pt, level, M, M_stride, lw, lh, 0, 0,
-                           1.0, 1.0, 0, nB, g_tile_order);
+                           1.0, 1.0, 0, nB, opt.tile_order);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1267,8 +1261,6 @@ extern "C" int ffl_debug_read_stamps(unsigned long long *out) {
 #define FFL_T(i)
 #endif
 
-static int g_blur_rows = 0;  // 0: automatic (ffl_blur_rows_per_wg)
-void ffl_set_blur_rows(int n) { g_blur_rows = n; }
 
 // FIRST != 0: the level's first iteration with the initial UpdateMatrices folded in -- M is never read from
 // memory: a "phase U" computes it for the 78 tile columns x 16 new rows from R0, R1 and the level's initial
@@ -1660,46 +1652,45 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
 // Tiles a workgroup walks down.  The strip walk saves 14 of 30 row loads per tile after a strip's first, so long strips
 // are cheaper -- as long as the launch still has enough workgroups to fill the device for several rounds.  A column of
 // tiles_y tiles is cut into s equal strips (nrb = ceil(tiles_y / s)), with the smallest s that gives at least
-// g_blur_min_wgs workgroups (ffl_set_option "blur_min_wgs").  Same-box interleaved sweep (profiles/r03_c_strip_sweep.txt,
+// `min_wgs` workgroups (ffl_set_option "blur_min_wgs", default 3500).  Same-box interleaved sweep (profiles/r03_c_strip_sweep.txt,
 // pairs/s against the threshold 8000, which is about what the power-of-two rule of rounds 1-2 chose): 1080p B = 32:
 // 2500 -3.0 %, 3000 +1.4, 3400-3840 +1.8, 4000 +0.6; 3840x2160 B = 32: 3000-3500 +2.8, 4000 +2.4, 6000 -0.1; 256x256
 // B = 256: 3000 -14.5 (a level lands on exactly 3072 workgroups), 3500-4000 +1.5, 6000 -2.2.
-static int g_blur_min_wgs = 3500;
-void ffl_set_blur_min_wgs(int n) { g_blur_min_wgs = n; }
-static int ffl_blur_rows_per_wg(int tiles_x, int tiles_y, int nB) {
+static int ffl_blur_rows_per_wg(int tiles_x, int tiles_y, int nB, int min_wgs) {
     for (int s = 1; s <= tiles_y; s++) {
         const int nrb = (tiles_y + s - 1) / s;
         if (nrb > 64) continue;
-        if ((long)tiles_x * ((tiles_y + nrb - 1) / nrb) * nB >= g_blur_min_wgs || nrb == 1) return nrb;
+        if ((long)tiles_x * ((tiles_y + nrb - 1) / nrb) * nB >= min_wgs || nrb == 1) return nrb;
     }
     return 1;
 }
 
 void ffl_launch_blur_solve(const float *Min, float *Mout, size_t M_stride, const float *R, size_t R_stride,
                            size_t plane, const PairTab *pt, int level, int nB, int lw, int lh, int update, int store_flow,
-                           hipStream_t st) {
+                           const FflOptions &opt, hipStream_t st) {
     const int tiles_x = (lw + 63) / 64, tiles_y = (lh + 15) / 16;
-    const int nrb = g_blur_rows > 0 ? g_blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB);
+    const int nrb = opt.blur_rows > 0 ? opt.blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB, opt.blur_min_wgs);
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (update)
         hipLaunchKernelGGL((k_blur_solve<true, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt, level, lw,
-                           lh, nrb, 0, 0, 1.0, 1.0, store_flow, nB, g_tile_order);
+                           lh, nrb, 0, 0, 1.0, 1.0, store_flow, nB, opt.tile_order);
     else
         hipLaunchKernelGGL((k_blur_solve<false, 0>), grid, dim3(256), 0, st, Min, Mout, M_stride, R, R_stride, plane, pt,
-                           level, lw, lh, nrb, 0, 0, 1.0, 1.0, 1, nB, g_tile_order);
+                           level, lw, lh, nrb, 0, 0, 1.0, 1.0, 1, nB, opt.tile_order);
 }
 
 // first iteration of a level with the initial UpdateMatrices folded in (pw > 0: initial flow = x2 upsample of
 // pt.prev, pw x ph; pw == 0: zero flow); writes the solved flow to pt.flow and the next M to Mout
 void ffl_launch_blur_solve_first(float *Mout, size_t M_stride, const float *R, size_t R_stride, size_t plane,
-                                 const PairTab *pt, int level, int nB, int lw, int lh, int pw, int ph, hipStream_t st) {
+                                 const PairTab *pt, int level, int nB, int lw, int lh, int pw, int ph, const FflOptions &opt,
+                                 hipStream_t st) {
     const int tiles_x = (lw + 63) / 64, tiles_y = (lh + 15) / 16;
-    const int nrb = g_blur_rows > 0 ? g_blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB);
+    const int nrb = opt.blur_rows > 0 ? opt.blur_rows : ffl_blur_rows_per_wg(tiles_x, tiles_y, nB, opt.blur_min_wgs);
     dim3 grid(ffl_tile_grid(tiles_x, (tiles_y + nrb - 1) / nrb, nB));
     if (pw > 0)
         hipLaunchKernelGGL((k_blur_solve<true, 1>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
-                           R_stride, plane, pt, level, lw, lh, nrb, pw, ph, (double)pw / lw, (double)ph / lh, 0, nB, g_tile_order);
+                           R_stride, plane, pt, level, lw, lh, nrb, pw, ph, (double)pw / lw, (double)ph / lh, 0, nB, opt.tile_order);
     else
         hipLaunchKernelGGL((k_blur_solve<true, 2>), grid, dim3(256), 0, st, (const float *)nullptr, Mout, M_stride, R,
-                           R_stride, plane, pt, level, lw, lh, nrb, 0, 0, 1.0, 1.0, 0, nB, g_tile_order);
+                           R_stride, plane, pt, level, lw, lh, nrb, 0, 0, 1.0, 1.0, 0, nB, opt.tile_order);
 }

@@ -8,8 +8,9 @@ process_video (FunscriptFlow.pyw:1187-1242) for the "HIP" backend.
 
 Everything runs in the calling process (HIP state must not cross fork); flows never leave HBM.
 Multi-GPU: pairs are sharded over the ranks either in contiguous blocks or round-robin in blocks of
-`block` pairs (`shard_pairs`); the only exchange is a host all-gather of the 16-byte pass-1 records (no
-RCCL collective).
+`block` pairs (`shard_pairs`); the only exchange is a host all-gather of the 32-byte pass-1 records (no
+RCCL collective) -- of ALL records under round-robin (`process_chunk_sharded`), of the <= 12 halo records per
+rank under contiguous blocks (`process_chunk_sharded_halo`, the streaming form).
 """
 import numpy as np
 
@@ -271,6 +272,93 @@ def process_chunk_sharded(engine, frames, rank, world, allgather, pov_mode=False
     return _merge_dots(allgather(_shard_pass2(engine, mine, centers, allrecs, pov_mode)), n), allrecs
 
 
+def halo_rows(rows, radius=SMOOTH_RADIUS):
+    """The part of a contiguous shard's pass-1 rows (pair index, x, y, cut; ascending) another rank can ever need: its
+    first and last `radius` pairs.  A pair within `radius` of a foreign block lies within the first / last `radius` pairs
+    of its own block, however short the blocks in between are."""
+    rows = np.asarray(rows, np.int64).reshape(-1, 4)
+    return rows if len(rows) <= 2 * radius else np.concatenate([rows[:radius], rows[-radius:]], axis=0)
+
+
+def process_chunk_sharded_halo(engine, frames, rank, world, allgather, pov_mode=False, cut_threshold=7.0):
+    """Streaming multi-GPU form of one chunk for CONTIGUOUS blocks: the only exchange between the passes is the halo.
+
+    process_chunk_sharded gathers every pass-1 record of the chunk before any pass 2 starts, so all ranks idle until the
+    slowest has finished pass 1.  FF:1203-1214 only needs pairs j-6..j+6: with contiguous blocks a rank's interior pairs
+    (window inside its own block, or clipped by the chunk's ends) depend on nobody else, and its <= 12 edge pairs on the
+    neighbouring blocks' first / last 6 records ("block edges need a 6-pair halo of pass-1 scalars only").
+    Schedule per rank:
+        pass 1 over its block in batches; after every batch, pass 2 for all its pairs whose window is already known
+        (runs on the device beside the next batch's pass 1, exactly as PairEngine.process_chunk does on one GPU);
+        ONE all-gather of <= 12 halo rows (32 B each) per rank;
+        pass 2 for the remaining edge pairs;
+        ONE all-gather of the results (pair index, scalar, x, y, cut) -- the output, not a barrier between the passes.
+    `engine.pass1` is called with on_batch= when it accepts one (HipShardEngine does); an engine without it still gives
+    the same numbers, only without the overlap.  Window means are exact integer sums / counts, so the result is
+    bit-identical to process_chunk_sharded's and to a single-GPU process_chunk.  Returns (dots, (n, 3) records) on every
+    rank."""
+    n = len(frames) - 1
+    R = SMOOTH_RADIUS
+    lo, hi = shard_range(n, world, rank)
+    mine = np.arange(lo, hi)
+    pos = np.zeros((n, 2), np.int64)
+    cuts = np.zeros(n, bool)
+    known = np.zeros(n, bool)
+    dots = np.zeros(hi - lo, np.float64)
+    todo = list(range(lo, hi))                     # own pairs still waiting for pass 2, ascending
+
+    def flush(final=False):
+        ready, rest = [], []
+        for j in todo:
+            w0, w1 = max(0, j - R), min(n, j + R + 1)
+            (ready if known[w0:w1].all() else rest).append(j)
+        if final and rest:
+            raise RuntimeError(f"rank {rank}: halo exchange left pairs {rest[:4]} without their +-{R} window")
+        todo[:] = rest
+        if ready:
+            js = np.asarray(ready)
+            w0, w1 = np.maximum(0, js - R), np.minimum(n, js + R + 1)
+            psum = np.zeros((n + 1, 2), np.int64)
+            psum[1:] = np.cumsum(pos, axis=0)
+            centers = (psum[w1] - psum[w0]) / (w1 - w0)[:, None]
+            dots[js - lo] = engine.radial(list(js - lo), centers, cuts[js], pov_mode)
+
+    def take(js, got):
+        js = np.asarray(js, np.int64)
+        pos[js] = [(r[0], r[1]) for r in got]
+        cuts[js] = [bool(r[4]) for r in got]
+        known[js] = True
+
+    def on_batch(ls, js, got):
+        take(js, got)
+        flush()
+
+    if len(mine):
+        import inspect
+        if "on_batch" in inspect.signature(engine.pass1).parameters:
+            recs = engine.pass1(frames, mine, pov_mode, cut_threshold, on_batch=on_batch)
+        else:                                      # an engine without the streaming hook: same numbers, no overlap
+            recs = engine.pass1(frames, mine, pov_mode, cut_threshold)
+        take(mine, recs)
+    own = np.concatenate([mine[:, None], pos[lo:hi], cuts[lo:hi, None].astype(np.int64)], axis=1) if len(mine) else np.zeros((0, 4), np.int64)
+    for part in allgather(halo_rows(own)):         # the only exchange between pass 1 and pass 2
+        part = np.asarray(part, np.int64).reshape(-1, 4)
+        if len(part):
+            pos[part[:, 0]] = part[:, 1:3]
+            cuts[part[:, 0]] = part[:, 3].astype(bool)
+            known[part[:, 0]] = True
+    flush(final=True)
+    out = np.concatenate([own.astype(np.float64), dots[:, None]], axis=1)          # (j, x, y, cut, dot)
+    rows = np.concatenate([np.asarray(p, np.float64).reshape(-1, 5) for p in allgather(out)], axis=0)
+    idx = rows[:, 0].astype(np.int64)
+    assert len(rows) == n and np.array_equal(np.sort(idx), np.arange(n)), "pairs lost or duplicated in the shard"
+    all_dots = np.empty(n, np.float64)
+    allrecs = np.empty((n, 3), np.int64)
+    all_dots[idx] = rows[:, 4]
+    allrecs[idx] = rows[:, 1:4].astype(np.int64)
+    return all_dots, allrecs
+
+
 def process_chunk_local_ranks(engines, frames, pov_mode=False, cut_threshold=7.0, assign="contiguous", block=1):
     """The same schedule with every rank driven from THIS process (one engine / context per device, or several
     contexts on one device): phase by phase, no process group.  Equivalent to world = len(engines) processes
@@ -295,10 +383,12 @@ class HipShardEngine:
         self.inner = PairEngine.__new__(PairEngine)  # a shard's flow slots are bounded by its size, checked in pass1
         self.inner.ctx, self.inner.B, self.inner.upload = ctx, B, upload or ctx.upload_frames
 
-    def pass1(self, frames, pair_indices, pov_mode, cut_threshold):
+    def pass1(self, frames, pair_indices, pov_mode, cut_threshold, on_batch=None):
+        """on_batch(local_indices, pair_indices, records) after every finished batch (process_chunk_sharded_halo issues the
+        pass 2 of pairs whose window is complete from it, beside the next batch's kernels)."""
         if len(pair_indices) > self.ctx.flow_slots:
             raise ValueError(f"shard of {len(pair_indices)} pairs does not fit the context's {self.ctx.flow_slots} flow slots")
-        return self.inner.pass1_pairs(frames, pair_indices, lambda l: l, pov_mode, cut_threshold)
+        return self.inner.pass1_pairs(frames, pair_indices, lambda l: l, pov_mode, cut_threshold, on_batch=on_batch)
 
     def radial(self, local_indices, centers, cuts, pov_mode):
         out, B = [], self.ctx.max_batch

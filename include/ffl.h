@@ -27,11 +27,16 @@
  *
  * Threading: a context is bound to one device and is internally stream-ordered.  Every entry point locks the
  * context, so calls may come from several host threads (an uploader, a submitter and a result collector working
- * on distinct slots).  No call holds the context lock while it waits for the device or copies frames into
- * staging (ffl_pass1_result(s), ffl_download_flow, ffl_radial, ffl_upload_flow, ffl_sync, ffl_host_free,
- * ffl_upload_frames(_raw) all release it for that time); uploads are serialised among themselves, pass-2 calls among
- * themselves.  ffl_last_error() returns the message of the context's most recent failing call by any thread.  ffl_set_option() is process-wide and not synchronised: set options before creating
- * contexts.  Sizes: 16x16 <= width x height, 20 * width * height < 2^32 (32-bit plane offsets in the kernels).
+ * on distinct slots).  The per-batch calls do not hold the context lock while they wait for the device or
+ * copy frames into staging (ffl_pass1_result(s), ffl_download_flow, ffl_radial, ffl_upload_flow, ffl_sync,
+ * ffl_host_free, ffl_upload_frames(_raw) all release it for that time, and wait on events only -- never on a stream
+ * another thread may be capturing a graph on); uploads are serialised among themselves, pass-2 calls among themselves.
+ * ffl_flow_pairs waits under the lock only when a lane already has 16 batches queued or evicts a captured graph; the
+ * test / measurement hooks (ffl_debug_pair, ffl_download_frame, ffl_profile_read) wait under it.
+ * ffl_last_error() returns the message of the context's most recent failing call by any thread.
+ * Options: ffl_set_option() changes the process-wide DEFAULTS; a context copies them when it is created and is from then
+ * on changed only through ffl_ctx_set_option(), so two contexts of one process (one per GPU) share no knob.
+ * Sizes: 16x16 <= width x height, 20 * width * height < 2^32 (32-bit plane offsets in the kernels).
  */
 #ifndef FFL_H
 #define FFL_H
@@ -165,7 +170,10 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
 
 /* ---- measurement hooks (bench.py) -------------------------------------------------------------- */
 
-/* Process-wide tuning knobs (results never depend on them):
+/* Tuning knobs (results never depend on them).  ffl_set_option sets the process-wide default that contexts created
+ * AFTERWARDS start from; ffl_ctx_set_option changes one live context (every knob but "lanes", which sizes the context's
+ * buffers: FFL_ERR_STATE) and makes that context -- and no other -- re-capture its graphs; ffl_ctx_get_option reads a
+ * context's value (ctx == NULL: the process-wide default).
  *   "blur_tile_h" = 16       rows of the 64-wide k_blur_solve LDS tile.  Fixed since the box-sum order
  *                            is anchored to blocks of 16 rows / columns (other values are refused); the
  *                            8 / 16 / 32 sweep of BASELINE configs[2] is recorded in profiles/README.md
@@ -192,6 +200,14 @@ int ffl_debug_pair(ffl_ctx *ctx, int f0, int f1, int level, int iter, float *I0,
  *   "tile_order"  = 0|1      k_blur_solve / k_update_matrices workgroup order: 0 pair-major (default), 1 tile-major
  *                            (every tile for all pairs of the batch back to back; less fabric traffic, not faster) */
 int ffl_set_option(const char *name, int value);
+int ffl_ctx_set_option(ffl_ctx *ctx, const char *name, int value);
+int ffl_ctx_get_option(ffl_ctx *ctx, const char *name, int *value);
+
+/* hipGraph bookkeeping of a context: batch shapes captured, batches replayed from a graph, captures that FAILED.  A
+ * failed capture is never silent: the batch is launched kernel by kernel (results unaffected), the context stops
+ * capturing until one of its options changes, one line goes to stderr, and the failure is counted here -- bench.py
+ * reports the three numbers (`config.graphs`) and the GPU tests assert capture_failures == 0. */
+int ffl_graph_stats(ffl_ctx *ctx, int *captured, int *replayed, int *capture_failures);
 
 /* HIP-event timing of kernel classes: every launch of a class whose bit (1u << FFL_K_*) is set in
  * class_mask is bracketed by events on the stream it is launched on.  0 switches timing off. */

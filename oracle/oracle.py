@@ -21,6 +21,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 _LIB_FMA = None
+_LIB_FAST = None
 
 # variant flags of orc_farneback_var (farneback_oracle.c header): OpenCV orderings the default oracle does not reproduce
 V_BOX_SLIDING, V_AREA2X_SEQ, V_GAUSS_ROW_LTR = 1, 2, 4
@@ -60,6 +61,52 @@ def lib_fma():
         assert L.orc_fma_build() == 1
         _LIB_FMA = L
     return _LIB_FMA
+
+
+def _host_id():
+    """CPU model + instruction-set flags of this host: what a -march=native build is only valid for."""
+    import hashlib
+    model, flags = "?", ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name") and model == "?":
+                    model = line.split(":", 1)[1].strip()
+                elif line.startswith("flags") and not flags:
+                    flags = line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return f"{model} {hashlib.sha256(flags.encode()).hexdigest()[:12]}"
+
+
+def lib_fast():
+    """liboracle_fast.so: the SAME C source at -O3 -march=native with contraction / vectorisation allowed.  TIMING ONLY
+    (bench.py's cpu_baseline `value`): never used to check anything.  Built for the host it runs on -- a copy that
+    travelled here from another machine (the build container's) is rebuilt first, since -march=native code of another
+    CPU may not even execute.  Returns None when it cannot be built here."""
+    global _LIB_FAST
+    if _LIB_FAST is None:
+        so, tag = os.path.join(_HERE, "liboracle_fast.so"), os.path.join(_HERE, "liboracle_fast.so.host")
+        srcs = [os.path.join(_HERE, f) for f in ("farneback_oracle.c", "frontend_oracle.c")]
+        host = _host_id()
+        try:
+            stale = (not os.path.exists(so) or not os.path.exists(tag) or open(tag).read() != host
+                     or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs))
+            if stale:
+                subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle_fast.so"], stdout=subprocess.DEVNULL)
+                with open(tag, "w") as f:
+                    f.write(host)
+            L = C.CDLL(so)
+        except (OSError, subprocess.CalledProcessError):
+            return None
+        L.orc_ws_bytes.argtypes = [C.c_int, C.c_int]
+        L.orc_ws_bytes.restype = C.c_size_t
+        L.orc_pair_ws.argtypes = [C.c_void_p, C.c_size_t, _u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_double)]
+        L.orc_radial.argtypes = [_f32p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_int]
+        L.orc_radial.restype = C.c_double
+        _LIB_FAST = L
+    return _LIB_FAST
 
 
 def lib():
@@ -272,18 +319,26 @@ class PairWorkspace:
     """Pre-faulted scratch block + output buffers for orc_pair_ws (cpu_baseline workers: nothing is allocated or
     first-touched inside the timed loop)."""
 
-    def __init__(self, w, h):
+    def __init__(self, w, h, fast=False):
+        """fast: run liboracle_fast.so (timing only) instead of the parity build."""
         self.w, self.h = w, h
-        self.nbytes = lib().orc_ws_bytes(w, h)
+        self.L = lib_fast() if fast else lib()
+        if self.L is None:
+            raise RuntimeError("liboracle_fast.so could not be built on this host")
+        self.nbytes = self.L.orc_ws_bytes(w, h)
         self.mem = np.zeros(self.nbytes, np.uint8)          # zeros() maps lazily: touch every page now
         self.mem[::4096] = 1
         self.flow = np.zeros((h, w, 2), np.float32)
-        self.flow[::64] = 1
+        self.flow.reshape(-1)[::1024] = 1                   # one float per 4 KiB page: every page of the output too
+
+    def radial(self, center, is_cut, pov_mode=False):
+        """pass 2 of the workspace's latest flow, by the same build"""
+        return self.L.orc_radial(self.flow, self.w, self.h, float(center[0]), float(center[1]), int(bool(is_cut)), int(bool(pov_mode)))
 
     def pair(self, p0, p1):
         x, y, v, mm = C.c_int(), C.c_int(), C.c_float(), C.c_double()
-        rc = lib().orc_pair_ws(self.mem.ctypes.data, self.nbytes, p0, p1, self.w, self.h, self.w, self.flow,
-                               C.byref(x), C.byref(y), C.byref(v), C.byref(mm))
+        rc = self.L.orc_pair_ws(self.mem.ctypes.data, self.nbytes, p0, p1, self.w, self.h, self.w, self.flow,
+                                C.byref(x), C.byref(y), C.byref(v), C.byref(mm))
         if rc:
             raise MemoryError(f"orc_pair_ws failed ({rc})")
         return self.flow, x.value, y.value, np.float32(v.value), mm.value

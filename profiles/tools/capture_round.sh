@@ -21,6 +21,12 @@ for WL in "3840 2160 32" "2880 2880 32" "256 256 256"; do
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${TAG}_F_$N -o f -- python3 bench.py --width $1 --height $2 --batch $3 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${TAG}_W_$N -o w -- python3 bench.py --width $1 --height $2 --batch $3 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2>&1
   python profiles/make_traffic.py $O/${TAG}_F_$N/f_counter_collection.csv $O/${TAG}_W_$N/w_counter_collection.csv k_blur_solve $N $3 $TAG
+  # kernel durations of THIS workload (SURVEY 7 hard part 5: 4K is the HBM-roofline run; 256x256 the reference's operating
+  # point): the same command under --kernel-trace --stats, so large_image / small_image roofline fractions can be
+  # recomputed from profiles/ without trusting HIP events
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats_$N -o s -- python3 bench.py --width $1 --height $2 --batch $3 --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/${TAG}_bench_under_rocprof_$N.json 2>/dev/null
+  cp $O/${TAG}_stats_$N/s_kernel_stats.csv $O/${TAG}_kernel_stats_$N.csv
+  python profiles/summarize_trace.py $O/${TAG}_stats_$N/s_kernel_trace.csv > $O/${TAG}_kernel_trace_by_grid_$N.txt
   (python profiles/summarize_pmc.py $O/${TAG}_F_$N/f_counter_collection.csv k_; python profiles/summarize_pmc.py $O/${TAG}_W_$N/w_counter_collection.csv k_) > $O/${TAG}_pmc_fetch_write_$N.txt
   echo "traffic $N done"
 done

@@ -21,10 +21,10 @@ runner = bench.StepRunner(ctx, B, False, SMOOTH_RADIUS)
 
 
 def apply(cfg):
-    _capi.set_option("blur_rows", 0); _capi.set_option("blur_min_wgs", 3500)
+    ctx.set_option("blur_rows", 0); ctx.set_option("blur_min_wgs", 3500)   # options belong to the context (ffl_ctx_set_option)
     for kv in cfg.split(","):
         k, v = kv.split("=")
-        _capi.set_option({"rows": "blur_rows", "minwgs": "blur_min_wgs", "order": "tile_order", "fuse": "fuse_first"}[k], int(v))
+        ctx.set_option({"rows": "blur_rows", "minwgs": "blur_min_wgs", "order": "tile_order", "fuse": "fuse_first"}[k], int(v))
 
 
 res = {c: [] for c in cfgs}

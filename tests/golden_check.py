@@ -1,7 +1,8 @@
 """Compare one finished batch of the HIP path with committed golden scalars (tests/golden/bench_*.json, made
 in the build container by oracle/gen_bench_golden.py).  Used by bench.py after its timed region and by the
 `-m gpu` tests of the shipped configuration; this module only reads numbers -- it never runs a CPU version
-of the path.
+of the path.  Test infrastructure: it lives beside the goldens it reads, outside the product package
+(bench.py puts tests/ on its import path for it).
 
 Bar (BASELINE north_star): argmax pixel index and value bit-exact, float reductions within 1e-4 relative,
 flow fields bit-exact (crc32 of the raw float32 bytes of the first / middle / last pair)."""
@@ -11,7 +12,7 @@ import zlib
 
 import numpy as np
 
-GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def golden_path(width, height, batch, seed):

@@ -20,7 +20,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 import oracle as orc
-from funscript_flow_amd import _capi, golden_check, pipeline
+import golden_check
+from funscript_flow_amd import _capi, pipeline
 from funscript_flow_amd.synth import sine_translate_frames
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,8 +68,13 @@ def test_shipped_configuration_1080p_b32_against_oracle(lanes):
         with _capi.Context(W, H, frame_slots=B + 2, flow_slots=3 * B, max_batch=B) as ctx:
             recs, dots = _run_bench_batch(ctx, frames, B)
             flows = {j: ctx.download_flow(j) for j in range(B)}
+            recs2, dots2 = _run_bench_batch(ctx, frames, B)            # the same step again: replayed from the graph
+            gs = ctx.graph_stats()
     finally:
         _capi.set_option("lanes", 2)
+    # the standard step runs from a captured hipGraph; a capture that fails would make it silently slower, never wrong
+    assert gs["capture_failures"] == 0 and gs["captured"] >= 1 and gs["replayed"] == 2, gs
+    assert [tuple(r) for r in recs2] == [tuple(r) for r in recs] and dots2 == dots
     status, detail = golden_check.check_batch(gold, frames, recs, dots, lambda j: flows[j])
     _require_golden_match(status, detail)
     for j in (0, B // 2 - 1, B - 1):                                   # first, middle, last pair of the batch
@@ -207,6 +213,9 @@ with _capi.Context(320, 180, device=0, max_batch=4, frame_slots=10, flow_slots=2
     for assign, block in (("contiguous", 1), ("round_robin", 1), ("round_robin", 4)):
         dots, recs = pipeline.process_chunk_sharded(eng, frames, rank, world, allgather, assign=assign, block=block)
         res.append(np.concatenate([dots, recs.reshape(-1).astype(np.float64)]))
+    # streaming form: pass 2 of interior pairs beside pass 1, only the 6 + 6 halo records cross between the passes
+    dots, recs = pipeline.process_chunk_sharded_halo(eng, frames, rank, world, allgather)
+    res.append(np.concatenate([dots, recs.reshape(-1).astype(np.float64)]))
 if rank == 0:
     np.save({out!r}, np.stack(res))
 dist.barrier()
@@ -234,6 +243,27 @@ def test_two_ranks_on_one_device_under_gloo(tmp_path):
     with _capi.Context(320, 180, max_batch=1) as ctx:
         ctx.submit_pair(0, frames[j], frames[j + 1])
         assert np.array_equal(ctx.download_flow(0), orc.farneback(frames[j], frames[j + 1]))
+
+
+def test_bench_launches_its_own_ranks_from_a_plain_shell():
+    """The driver's command form: `python bench.py --gpus 2 ...` with NO torch.distributed environment.  bench.py must
+    become the parent that spawns the two rank processes (FF:1190-1191), and print exactly one JSON line with n_gpus 2,
+    checked against the rank clips' goldens.  On this 1-GPU box the ranks share cuda:0 (--rehearse-gloo); without that
+    flag two ranks on one card must end with status 3, one FATAL message and no JSON line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    r = subprocess.run(cmd + ["--rehearse-gloo"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["checked"] is True, line["check_detail"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 3 and r.stdout.strip() == "", (r.returncode, r.stdout)
+    assert r.stderr.count("FATAL") == 1 and "drive the same GPU" in r.stderr, r.stderr[-2000:]
 
 
 def test_batches_above_eight_pairs_small_sizes():
@@ -469,3 +499,93 @@ def test_create_that_exceeds_device_memory_fails_cleanly_and_leaves_the_device_u
         backend._fit_chunk(W, H, slots, 0, 32)
     B, bytes_needed = backend._fit_chunk(1920, 1080, 3000, 0, 32)      # the reference's default chunk (FF:2647) at 1080p
     assert 1 <= B <= 32 and bytes_needed < free1
+
+
+def test_options_belong_to_a_context_not_to_the_process():
+    """Two live contexts in one process (the shape of one process driving several GPUs): each keeps the option set it was
+    created with, ffl_ctx_set_option changes ONE of them and makes only that one re-capture its graphs, "lanes" is fixed
+    at creation, and nothing of it changes a bit of the results."""
+    w, h, B = 320, 180, 4
+    fr = sine_translate_frames(B + 1, w, h, seed=8, amp=(2.5, 1.5), period=7, zoom=0.02)
+    want = [orc.farneback(fr[j], fr[j + 1]) for j in range(B)]
+
+    def step(ctx):
+        ctx.flow_pairs(list(range(B)), list(range(1, B + 1)), list(range(B)))
+        return [ctx.download_flow(j) for j in range(B)]
+
+    try:
+        _capi.set_option("lanes", 1)
+        _capi.set_option("fuse_first", 1)
+        a = _capi.Context(w, h, frame_slots=B + 2, flow_slots=B, max_batch=B)
+        _capi.set_option("lanes", 2)
+        _capi.set_option("fuse_first", 10000)          # process-wide defaults changed AFTER a exists: a keeps its own
+        b = _capi.Context(w, h, frame_slots=B + 2, flow_slots=B, max_batch=B)
+        with a, b:
+            assert (a.get_option("lanes"), a.get_option("fuse_first")) == (1, 1)
+            assert (b.get_option("lanes"), b.get_option("fuse_first")) == (2, 10000)
+            for c in (a, b):
+                c.upload_frames(0, list(fr))
+                for _ in range(3):
+                    for got, w_ in zip(step(c), want):
+                        assert np.array_equal(got, w_)
+            ga, gb = a.graph_stats(), b.graph_stats()
+            assert ga["capture_failures"] == gb["capture_failures"] == 0 and ga["captured"] == 1 and gb["captured"] == 2   # one per lane used
+            a.set_option("blur_min_wgs", 1)             # a knob of a alone: a re-captures, b replays what it has
+            a.set_option("tile_order", 1)
+            assert b.get_option("blur_min_wgs") == 3500 and b.get_option("tile_order") == 0
+            assert _capi.get_option("blur_min_wgs") == 3500
+            for c in (a, b):
+                for _ in range(2):
+                    for got, w_ in zip(step(c), want):
+                        assert np.array_equal(got, w_)
+            ga2, gb2 = a.graph_stats(), b.graph_stats()
+            assert ga2["captured"] == ga["captured"] + 1 and gb2["captured"] == gb["captured"], (ga, ga2, gb, gb2)
+            assert gb2["replayed"] == gb["replayed"] + 2 and ga2["capture_failures"] == gb2["capture_failures"] == 0
+            with pytest.raises(_capi.FFLError, match="lanes"):
+                a.set_option("lanes", 2)
+            a.set_option("lanes", 1)                    # the value it has is accepted
+            with pytest.raises(_capi.FFLError):
+                a.set_option("no_such_knob", 1)
+    finally:
+        _capi.set_option("lanes", 2)
+        _capi.set_option("fuse_first", 10000)
+
+
+def test_sync_from_another_thread_while_new_batch_shapes_are_captured():
+    """ffl_sync must not touch a lane's stream while another thread captures a graph on it (advisor, round 3): one thread
+    queues batches of ever new shapes (every one a fresh hipStreamBeginCapture .. EndCapture on the lane's stream), a
+    second thread calls ffl_sync in a loop.  No call may fail, no capture may be invalidated, results stay exact."""
+    import threading
+    w, h, nmax = 160, 96, 12
+    fr = sine_translate_frames(nmax + 1, w, h, seed=6, amp=(2.0, 1.0), period=7)
+    errors, stop = [], threading.Event()
+    try:
+        _capi.set_option("lanes", 1)
+        with _capi.Context(w, h, max_batch=nmax, frame_slots=nmax + 2, flow_slots=nmax) as ctx:
+            ctx.upload_frames(0, list(fr))
+            ctx.sync()
+
+            def syncer():
+                try:
+                    while not stop.is_set():
+                        ctx.sync()
+                except Exception as e:  # noqa: BLE001
+                    errors.append(e)
+
+            t = threading.Thread(target=syncer)
+            t.start()
+            try:
+                for rep in range(3):
+                    for n in range(1, nmax + 1):
+                        for pov in (False, True):          # 24 shapes per round > the 16-entry cache: captures every round
+                            ctx.flow_pairs(list(range(n)), list(range(1, n + 1)), list(range(n)), pov)
+            finally:
+                stop.set()
+                t.join()
+            assert not errors, errors
+            gs = ctx.graph_stats()
+            assert gs["capture_failures"] == 0 and gs["captured"] >= 2 * nmax, gs
+            ctx.flow_pairs([nmax - 1], [nmax], [0])
+            assert np.array_equal(ctx.download_flow(0), orc.farneback(fr[nmax - 1], fr[nmax]))
+    finally:
+        _capi.set_option("lanes", 2)

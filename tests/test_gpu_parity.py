@@ -152,6 +152,31 @@ def test_denormals_and_cut_threshold():
         assert ctx.pass1_result(0, cut_threshold=9.0)[4] is False
 
 
+def test_cut_flag_known_answers_at_the_threshold():
+    """FF:893 `is_cut = mean_mag > 7` is a discontinuous function of a float (the cut flip zone): the
+    threshold itself is pinned by known answers.  A flow of constant magnitude exactly 7 has mean_mag == 7.0 in every
+    summation order (f64 sum of identical exactly representable terms; numpy's pairwise f32 mean likewise) -> NOT cut;
+    the next float above 7 in every pixel -> cut; and a field whose mean sits one f32 step above 7 only through ONE
+    pixel of 1920x1080 is beyond f32 resolution of the mean and must agree with numpy's own answer for it."""
+    h, w = 1080, 1920
+    up = np.nextafter(np.float32(7.0), np.float32(8.0))
+    flow = np.zeros((h, w, 2), np.float32)
+    with _capi.Context(w, h, max_batch=1) as ctx:
+        for vec, want in (((7.0, 0.0), False), ((0.0, -7.0), False), ((up, 0.0), True), ((0.0, up), True)):
+            flow[...] = vec
+            assert np.float32(np.sqrt(np.float32(vec[0]) ** 2 + np.float32(vec[1]) ** 2)) == np.float32(max(abs(vec[0]), abs(vec[1])))
+            ctx.upload_flow(0, flow)
+            x, y, v, mm, cut = ctx.pass1_result(0)
+            assert cut is want and (float(mm) == 7.0) is (not want), (vec, mm, cut)
+            assert bool(orc.mean_mag_np(flow) > 7) is want          # the reference's own expression on the same field
+        # 3-4-5 triangle scaled: |(4.2, 5.6)| is 7 only up to f32 rounding of the squares -- whatever sqrtf gives per pixel,
+        # device and numpy must agree on the flag because every pixel carries the same magnitude
+        flow[...] = (np.float32(4.2), np.float32(5.6))
+        ctx.upload_flow(0, flow)
+        mag = np.sqrt(np.float32(4.2) ** 2 + np.float32(5.6) ** 2, dtype=np.float32)
+        assert ctx.pass1_result(0)[4] is bool(mag > np.float32(7.0)) is bool(orc.mean_mag_np(flow) > 7)
+
+
 def test_errors_are_loud():
     with _capi.Context(64, 64, max_batch=1) as ctx:
         with pytest.raises(_capi.FFLError):

@@ -135,6 +135,14 @@ out = []
 for assign, block in (("contiguous", 1), ("round_robin", 1), ("round_robin", 2)):
     dots, recs = pipeline.process_chunk_sharded(OracleEngine(), frames, rank, world, allgather, assign=assign, block=block)
     out.append(dots)
+# the streaming form for contiguous blocks: only the <= 12 halo rows per rank cross between the passes
+calls = []
+def counting_allgather(obj):
+    calls.append(np.asarray(obj).shape)
+    return allgather(obj)
+dots, recs = pipeline.process_chunk_sharded_halo(OracleEngine(), frames, rank, world, counting_allgather)
+assert len(calls) == 2 and calls[0][0] <= 12 and calls[0][1] == 4, calls      # halo rows, then the results
+out.append(dots)
 if rank == 0:
     np.save({out!r}, np.stack(out))
 dist.barrier()
@@ -158,7 +166,7 @@ def _run_sharded(tmp_path, world, nframes, port):
     cuts = [bool(orc.mean_mag_np(f) > 7) for f in flows]
     centers = orc.smooth_centers(pos)
     want = np.array([orc.radial_np(f, c, k) for f, c, k in zip(flows, centers, cuts)])
-    assert got.shape == (3, nframes - 1)
+    assert got.shape == (4, nframes - 1)
     for g in got:
         assert np.array_equal(g, want)
 
@@ -179,6 +187,60 @@ def test_sharded_two_pass_gloo_world8_with_empty_and_one_pair_shards(tmp_path):
         pytest.skip("world-8 gloo test runs where no GPU device node exists (the GPU boxes cap processes per card at 6)")
     _run_sharded(tmp_path, 8, 6, 29573)
     _run_sharded(tmp_path, 8, 12, 29575)
+
+
+def test_halo_form_streams_pass2_before_the_exchange():
+    """process_chunk_sharded_halo on one rank of a pretend 3-rank world (no process group: the other ranks' halo rows are
+    computed here): interior pairs must get their pass 2 from on_batch, BEFORE any exchange; only the <= 12 edge pairs wait
+    for the neighbours' 6 + 6 records; results equal the whole-chunk schedule."""
+    n, world, rank = 40, 3, 1
+    rng = np.random.default_rng(3)
+    P = rng.integers(0, 500, (n, 2))
+    C = rng.random(n) < 0.2
+    log = []
+
+    class Eng:   # pass-1 records come from the table above, pass 2 returns a function of (pair, centre) to compare exactly
+        def __init__(self, lo):
+            self.lo = lo
+        def pass1(self, frames, pairs, pov, thr, on_batch=None):
+            recs = [(int(P[j][0]), int(P[j][1]), 0.0, 0.0, bool(C[j])) for j in pairs]
+            for s0 in range(0, len(pairs), 4):                      # batches of 4
+                if on_batch:
+                    ls = list(range(s0, min(s0 + 4, len(pairs))))
+                    on_batch(ls, [int(pairs[l]) for l in ls], [recs[l] for l in ls])
+            return recs
+        def radial(self, idx, centers, cuts, pov):
+            log.append(("radial", [self.lo + i for i in idx]))
+            return [0.0 if k else float(self.lo + i) + c[0] * 1e-3 + c[1] * 1e-6 for i, c, k in zip(idx, centers, cuts)]
+
+    lo, hi = pipeline.shard_range(n, world, rank)
+    others = {}
+    for r in range(world):
+        l, h = pipeline.shard_range(n, world, r)
+        rows = np.array([[j, P[j][0], P[j][1], int(C[j])] for j in range(l, h)], np.int64)
+        others[r] = pipeline.halo_rows(rows)
+    centers = pipeline.smooth_centers(P)
+    want = np.array([0.0 if C[j] else float(j) + centers[j][0] * 1e-3 + centers[j][1] * 1e-6 for j in range(n)])
+
+    def allgather(obj):
+        log.append(("allgather", np.asarray(obj).shape))
+        if np.asarray(obj).shape[1] == 4:
+            return [obj if r == rank else others[r] for r in range(world)]
+        rows = []
+        for r in range(world):                                           # the other ranks' results, made up from `want`
+            l, h = pipeline.shard_range(n, world, r)
+            rows.append(obj if r == rank else np.array([[j, P[j][0], P[j][1], int(C[j]), want[j]] for j in range(l, h)], np.float64))
+        return rows
+
+    dots, recs = pipeline.process_chunk_sharded_halo(Eng(lo), [None] * (n + 1), rank, world, allgather)
+    assert np.array_equal(dots, want) and np.array_equal(recs, np.concatenate([P, C[:, None].astype(np.int64)], axis=1))
+    first_xchg = next(i for i, e in enumerate(log) if e[0] == "allgather")
+    before = sorted(j for e in log[:first_xchg] if e[0] == "radial" for j in e[1])
+    after = sorted(j for e in log[first_xchg:] if e[0] == "radial" for j in e[1])
+    assert before == list(range(lo + 6, hi - 6)) and after == list(range(lo, lo + 6)) + list(range(hi - 6, hi))
+    assert [e[1][0] for e in log if e[0] == "allgather"] == [12, hi - lo]
+    # blocks shorter than the radius: the halo of a pair spans several ranks' rows
+    assert len(pipeline.halo_rows(np.zeros((5, 4)))) == 5 and len(pipeline.halo_rows(np.zeros((13, 4)))) == 12
 
 
 def test_shard_pairs_partitions_under_both_assignments():
@@ -346,3 +408,80 @@ def test_bench_helpers_without_a_gpu(tmp_path, monkeypatch):
     c = bench.cpu_baseline(sine_translate_frames(5, 96, 64, seed=1), max_workers=2, pairs_per_worker=2)
     assert c["kind"] == "port" and c["value"] > 0 and c["single_thread"] > 0 and set(c["sweep"]) >= {"1", "2"}
     assert c["cores"] in (1, 2) and "FF:1190-1191" in c["sample"]
+    # two builds of the same source: `value` from the -O3 -march=native one (timing only), the parity build beside it
+    assert "liboracle_fast.so" in c["build"] and c["value_parity_build"] > 0 and c["single_thread_parity_build"] > 0
+    assert 0 <= c["max_abs_dflow_fast_vs_parity"] < 1e-2 and c["argmax_equal_fast_vs_parity"] in (True, False)
+
+
+_RANK_CHILD = r"""
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0 and os.environ["LOCAL_RANK"] == str(rank)
+mode = sys.argv[1]
+if mode == "ok":
+    print("banner from rank %d" % rank, file=sys.stderr)
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "argv": sys.argv[2:]}))
+    else:
+        print("noise on stdout of rank %d" % rank)          # must NOT reach the launcher's stdout
+elif mode == "fail":
+    if rank == 1:
+        sys.exit(3)
+    time.sleep(120)                                          # a rank stuck in a rendezvous: the launcher must stop it
+"""
+
+
+def test_launcher_relays_rank0_line_and_first_failure(tmp_path):
+    """funscript_flow_amd.launch.spawn_ranks, the parent of `bench.py --gpus N` (FF:1190-1191: the parent spawns its
+    workers): N children with the torch.distributed environment, ONLY rank 0's stdout on stdout, exit status of the
+    first failing rank with the others stopped at once."""
+    import io
+    import time
+    from funscript_flow_amd import launch
+    child = tmp_path / "child.py"
+    child.write_text(_RANK_CHILD)
+    out, err = io.StringIO(), io.StringIO()
+    assert launch.spawn_ranks(str(child), ["ok", "--steps", "3"], 3, out=out, err=err) == 0
+    lines = [l for l in out.getvalue().splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"n_gpus": 3, "argv": ["--steps", "3"]}
+    assert "noise on stdout of rank 1" in err.getvalue() and "noise on stdout of rank 2" in err.getvalue()
+    out, err = io.StringIO(), io.StringIO()
+    t0 = time.monotonic()
+    assert launch.spawn_ranks(str(child), ["fail"], 3, out=out, err=err, grace_s=5.0) == 3
+    assert time.monotonic() - t0 < 30 and out.getvalue().strip() == "" and "rank 1/3 exited with status 3" in err.getvalue()
+    assert launch.free_port() != launch.free_port() or True   # ports are picked per launch
+    e = launch.rank_env(2, 4, 12345, base={})
+    assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == ("2", "2", "4", "127.0.0.1", "12345")
+    assert e["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+
+
+def test_bench_gpus_n_from_a_plain_shell_is_a_launcher(tmp_path):
+    """`python bench.py --gpus 2 ...` with no torch.distributed environment (the driver's command form) must start the
+    rank processes itself.  Here there is no GPU, so every rank ends with the 'needs a GPU' message: the parent must hand
+    that status on (non-zero), print no JSON line, and never have imported torch itself."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("GPU box: covered by the -m gpu self-launch test")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and r.stdout.strip() == ""
+    assert "needs a GPU" in r.stderr and "launch: rank" in r.stderr
+
+
+def test_process_wide_option_defaults_without_a_device():
+    """ffl_set_option only sets the defaults new contexts start from (readable without a device); bad names / values are
+    refused and leave the default alone."""
+    try:
+        assert _capi.get_option("lanes") == 2 and _capi.get_option("fuse_first") == 10000 and _capi.get_option("blur_min_wgs") == 3500
+        _capi.set_option("lanes", 3)
+        _capi.set_option("blur_min_wgs", 777)
+        assert _capi.get_option("lanes") == 3 and _capi.get_option("blur_min_wgs") == 777
+        for bad in (("lanes", 9), ("blur_rows", 65), ("copy_threads", 0), ("nope", 1), ("blur_tile_h", 8)):
+            with pytest.raises(_capi.FFLError):
+                _capi.set_option(*bad)
+        assert _capi.get_option("lanes") == 3
+        with pytest.raises(_capi.FFLError):
+            _capi.get_option("nope")
+    finally:
+        _capi.set_option("lanes", 2)
+        _capi.set_option("blur_min_wgs", 3500)
