@@ -135,9 +135,15 @@ _chunk_ctx = {}
 def _fit_chunk(width, height, n_pairs, device, max_batch, reclaim=0):
     """Largest batch size <= max_batch whose context (the chunk's flows resident + the lanes' work buffers, which
     scale with the batch) fits the device's FREE memory (hipMemGetInfo through the C ABI; `reclaim` = bytes a context
-    about to be closed gives back).  Raises with the numbers when even B = 1 does not fit."""
+    about to be closed gives back).  Raises with the numbers when even B = 1 does not fit.
+
+    ffl_estimate_bytes counts what ffl_create allocates.  Not in it, and covered by the 5 % margin plus a fixed reserve:
+    the raw-frame ring of ffl_upload_frames_raw (4 device buffers of one decoded source frame, grown on first use: 100 MB
+    for 4K sources), captured hipGraphs (KBs per batch shape) and the HIP runtime's own pools.  The page-locked bytes
+    (`pinned`: staging areas + result records) are host memory and do not count against the device."""
     free, total = _capi.device_mem_info(device)
-    budget = (free + reclaim) * 0.95
+    reserve = max(256 << 20, 4 * 3 * 4 * width * height)    # raw ring for sources up to 2x the context's size per axis
+    budget = (free + reclaim) * 0.95 - reserve
     B = max_batch
     while True:
         need, pinned = _capi.estimate_bytes(width, height, 2 * B + 2, max(n_pairs, 1), B)
