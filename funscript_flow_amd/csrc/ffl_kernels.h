@@ -246,11 +246,7 @@ __device__ __forceinline__ T *ffl_at(float *base, unsigned idx) {
 __device__ __forceinline__ ffl_f2u ffl_ld_corner(const float *plane_base, unsigned idx) {
     ffl_f2u v;
     v.x = *ffl_at<float>(plane_base, idx);
-#ifdef FFL_EXP_DPP_STANDIN  // timing only (WRONG for lane 63 and wherever neighbouring lanes are not neighbouring pixels)
-    v.y = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v.x), 0x130, 0xf, 0xf, false));
-#else
     v.y = *ffl_at<float>(plane_base, idx + 1u);
-#endif
     return v;
 }
 

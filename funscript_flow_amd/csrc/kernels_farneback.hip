@@ -1580,20 +1580,12 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
                 const int ly = (tid >> 6) + 4 * k;
                 const int y = min(y0 + ly, h - 1);
                 S.f = sF2[ly * FP + lx];
-#ifdef FFL_EXP_UMHOT   // timing only: the fused update's R0 / R1 reads always hit the same 16 KB (upper bound of what a prefetch could give)
-                const unsigned o = ((unsigned)y * (unsigned)w + (unsigned)x) & 0xFFFu;
-#else
                 const unsigned o = (unsigned)y * (unsigned)w + (unsigned)x;
-#endif
 #pragma unroll
                 for (int c = 0; c < 5; c++) S.r0[c] = *ffl_at<float>(R0 + c * plane, o);
                 const UmLoc L = ffl_um_locate(w, h, x, y, S.f.x, S.f.y);
                 S.a00 = L.a00; S.a01 = L.a01; S.a10 = L.a10; S.a11 = L.a11; S.inside = L.inside;
-#ifdef FFL_EXP_UMHOT
-                const unsigned o1 = (L.inside ? (unsigned)L.y1 * (unsigned)w + (unsigned)L.x1 : 0u) & 0xFFFu;
-#else
                 const unsigned o1 = L.inside ? (unsigned)L.y1 * (unsigned)w + (unsigned)L.x1 : 0u;
-#endif
 #pragma unroll
                 for (int c = 0; c < 5; c++) {
                     S.t[c] = ffl_ld_corner(R1 + c * plane, o1);
