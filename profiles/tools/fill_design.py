@@ -81,6 +81,8 @@ vals = {
     "CPUPW": f"{cpu['per_worker_vs_single_at_value']:.2f}", "CPUQ": f"{cpu['cpu_quota_cores']:.0f}" if cpu.get("cpu_quota_cores") else "none",
     "CPUSWEEP": ", ".join(f"{k}: {v['pairs_per_s']:.1f}" for k, v in cpu["sweep"].items()),
     "RATIO": f"{b['value'] / cpu['value']:.0f}",
+    "CPUP": f"{cpu.get('value_parity_build', float('nan')):.1f}", "CPUP1": f"{cpu.get('single_thread_parity_build', float('nan')):.2f}",
+    "CPUD": f"{cpu.get('max_abs_dflow_fast_vs_parity', float('nan')):.1e}",
 }
 tmpl = open(os.path.join(ROOT, "profiles", "tools", "design_section7.tmpl")).read()
 missing = set(re.findall(r"@([A-Z0-9_]+)@", tmpl)) - set(vals)
