@@ -59,12 +59,14 @@ struct LevelGeom {
 // one host thread moves ~22 GB/s, a 1080p BGR stream at 5 k pairs/s needs 31.  A few persistent helper threads share
 // each large copy by rows (created on first use, joined in ffl_destroy).
 struct CopyPool {
+    // one share of a staging copy: global rows g0 .. g1-1 of a run of `nf` equally shaped frames (row g belongs to frame
+    // g / rows); frame f is read from srcs[f] (row pitch src_pitch) and lands at dst + f * dst_frame (rows packed)
     struct Job {
         uint8_t *dst;
-        const uint8_t *src;
-        size_t row_bytes;
-        ptrdiff_t dst_pitch, src_pitch;
-        int rows;
+        const uint8_t *const *srcs;
+        size_t row_bytes, dst_frame;
+        ptrdiff_t src_pitch;
+        int rows, g0, g1;
     };
     std::vector<std::thread> workers;
     std::mutex mu;
@@ -74,10 +76,18 @@ struct CopyPool {
     bool stop = false;
 
     static void run(const Job &j) {
-        if (j.dst_pitch == (ptrdiff_t)j.row_bytes && j.src_pitch == (ptrdiff_t)j.row_bytes)
-            memcpy(j.dst, j.src, j.row_bytes * (size_t)j.rows);
-        else
-            for (int y = 0; y < j.rows; y++) memcpy(j.dst + (ptrdiff_t)y * j.dst_pitch, j.src + (ptrdiff_t)y * j.src_pitch, j.row_bytes);
+        int g = j.g0;
+        while (g < j.g1) {
+            const int f = g / j.rows, y0 = g - f * j.rows;
+            const int y1 = (j.g1 - f * j.rows) < j.rows ? (j.g1 - f * j.rows) : j.rows;  // rows y0 .. y1-1 of frame f
+            uint8_t *d = j.dst + (size_t)f * j.dst_frame + (size_t)y0 * j.row_bytes;
+            const uint8_t *s = j.srcs[f] + (ptrdiff_t)y0 * j.src_pitch;
+            if (j.src_pitch == (ptrdiff_t)j.row_bytes)
+                memcpy(d, s, j.row_bytes * (size_t)(y1 - y0));
+            else
+                for (int y = y0; y < y1; y++, d += j.row_bytes, s += j.src_pitch) memcpy(d, s, j.row_bytes);
+            g += y1 - y0;
+        }
     }
     void start(int n) {
         jobs.resize(n);
@@ -97,27 +107,32 @@ struct CopyPool {
                 }
             });
     }
-    // rows x row_bytes from src (pitch src_pitch) to dst (pitch dst_pitch), split by rows over the helpers + the caller
-    void copy(uint8_t *dst, ptrdiff_t dst_pitch, const uint8_t *src, ptrdiff_t src_pitch, size_t row_bytes, int rows, int threads) {
-        const int parts = (row_bytes * (size_t)rows < (size_t)(1 << 20) || threads < 2) ? 1 : (threads < rows ? threads : rows);
+    // `nf` frames of rows x row_bytes (source row pitch src_pitch) into consecutive packed frames at dst, the run's rows
+    // split evenly over the helpers + the caller.  A run of many SMALL frames (257 frames of 64 KB per batch at the
+    // reference's 256x256 operating point) is shared like one large frame: copied frame by frame on the calling thread it
+    // cost 0.7 ms per batch -- half of what the device needs for the batch -- and made the host the bottleneck.
+    void copy(uint8_t *dst, const uint8_t *const *srcs, int nf, ptrdiff_t src_pitch, size_t row_bytes, int rows, int threads) {
+        const int total = nf * rows;
+        const int parts = (row_bytes * (size_t)total < (size_t)(1 << 20) || threads < 2) ? 1 : (threads < total ? threads : total);
         if (parts > 1 && (int)workers.size() < parts - 1) {
             // (re)size once; helpers are idle here because copy() is only called under the context's upload lock (up_mu)
             shutdown();
             stop = false;
             start(parts - 1);
         }
-        const int per = (rows + parts - 1) / parts;
-        {
+        const int per = (total + parts - 1) / parts;
+        const size_t dst_frame = row_bytes * (size_t)rows;
+        if (parts > 1) {
             std::unique_lock<std::mutex> lk(mu);
             for (int p = 1; p < parts; p++) {
-                const int y0 = p * per, n = rows - y0 < per ? rows - y0 : per;
-                if (n <= 0) continue;
-                jobs[p - 1] = {dst + (ptrdiff_t)y0 * dst_pitch, src + (ptrdiff_t)y0 * src_pitch, row_bytes, dst_pitch, src_pitch, n};
+                const int g0 = p * per, g1 = g0 + per < total ? g0 + per : total;
+                if (g0 >= g1) continue;
+                jobs[p - 1] = {dst, srcs, row_bytes, dst_frame, src_pitch, rows, g0, g1};
                 busy[p - 1] = 1;
             }
             cv_work.notify_all();
         }
-        run({dst, src, row_bytes, dst_pitch, src_pitch, per < rows ? per : rows});
+        run({dst, srcs, row_bytes, dst_frame, src_pitch, rows, 0, per < total ? per : total});
         if (parts > 1) {
             std::unique_lock<std::mutex> lk(mu);
             cv_done.wait(lk, [&] {
@@ -779,27 +794,30 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
         int rc = send(0, n);
         if (rc) return rc;
     } else {
-        int sent = 0;
-        size_t pending = 0;
         const int copy_threads = c->opt.copy_threads;
-        for (int i = 0; i < n; i++) {
-            const int fs = first + i;
-            // the previous transfer out of this slot's staging area must have left the host buffer; the wait and the
+        int i = 0;
+        while (i < n) {
+            // one piece: consecutive frames worth >= 8 MiB (or the rest of the run), staged together -- the piece's rows
+            // are shared by the copy threads -- and sent as one transfer
+            int j = i;
+            for (size_t bytes = 0; j < n && bytes < ((size_t)8 << 20); j++) bytes += fbytes;
+            // the previous transfers out of these slots' staging areas must have left the host buffer; the waits and the
             // staging copy run WITHOUT the context lock (up_mu keeps other uploaders out of the staging areas and the pool)
-            hipEvent_t prev = c->ev_uploaded[fs];
+            std::vector<hipEvent_t> prev;
+            for (int k = i; k < j; k++) {
+                hipEvent_t e = c->ev_uploaded[first + k];
+                if (e && (prev.empty() || prev.back() != e)) prev.push_back(e);
+            }
             lk.unlock();
-            hipError_t pe = prev ? hipEventSynchronize(prev) : hipSuccess;
-            if (pe == hipSuccess)
-                c->pool.copy(stage0 + (size_t)i * fbytes, (ptrdiff_t)row, frames[i], stride_bytes, row, height, copy_threads);
+            hipError_t pe = hipSuccess;
+            for (auto e : prev)
+                if (pe == hipSuccess) pe = hipEventSynchronize(e);
+            if (pe == hipSuccess) c->pool.copy(stage0 + (size_t)i * fbytes, frames + i, j - i, stride_bytes, row, height, copy_threads);
             lk.lock();
             HIPCHK(c, pe);
-            pending += fbytes;
-            if (pending >= ((size_t)8 << 20) || i == n - 1) {
-                int rc = send(sent, i + 1);
-                if (rc) return rc;
-                sent = i + 1;
-                pending = 0;
-            }
+            int rc = send(i, j);
+            if (rc) return rc;
+            i = j;
         }
     }
     hipEvent_t ev = c->up_ring[c->up_next++ % (2 * FFL_EV_RING)];
@@ -867,7 +885,7 @@ int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *fr
         if (!direct) {
             const int copy_threads = c->opt.copy_threads;
             lk.unlock();  // the staging copy runs without the context lock (up_mu protects the ring and the pool)
-            c->pool.copy(rb.h, (ptrdiff_t)fp.stride, data, stride_bytes, fp.stride, sh, copy_threads);
+            c->pool.copy(rb.h, &data, 1, stride_bytes, fp.stride, sh, copy_threads);
             lk.lock();
         }
         for (size_t l = 0; l < c->lanes.size(); l++) {  // batches still reading the slot's previous frame

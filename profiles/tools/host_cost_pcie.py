@@ -1,0 +1,41 @@
+"""Host-side breakdown of the PCIe-inclusive small-image path (pipeline.PairEngine over host ndarrays): wall time spent
+inside each binding call per batch, against the batch's total.  python profiles/tools/host_cost_pcie.py [W H B lanes]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch  # noqa: F401
+from funscript_flow_amd import _capi, pipeline
+from funscript_flow_amd.synth import sine_translate_frames
+
+W, H, B, lanes = (int(v) for v in (sys.argv[1:5] + ["256", "256", "256", "2"][len(sys.argv) - 1:]))
+_capi.set_option("lanes", lanes)
+base = sine_translate_frames(17, W, H, seed=1)
+nfr = 8 * B + 1
+frames = [base[i % 17] for i in range(nfr)]
+acc = {}
+
+
+def timed(obj, name):
+    f = getattr(obj, name)
+
+    def g(*a, **k):
+        t = time.perf_counter()
+        r = f(*a, **k)
+        acc[name] = acc.get(name, 0.0) + time.perf_counter() - t
+        return r
+    setattr(obj, name, g)
+
+
+with _capi.Context(W, H, max_batch=B, frame_slots=pipeline.min_frame_slots(B, 2), flow_slots=pipeline.min_flow_slots(B, 2)) as ctx:
+    for n in ("upload_frames", "flow_pairs", "pass1_results", "radial"):
+        timed(ctx, n)
+    eng = pipeline.PairEngine(ctx)
+    eng.process_chunk(frames[:2 * B + 1])
+    for rep in range(3):
+        acc.clear()
+        t0 = time.perf_counter()
+        eng.process_chunk(frames)
+        dt = time.perf_counter() - t0
+        nb = (nfr - 1) / B
+        print(f"{W}x{H} B={B} lanes={lanes}: {(nfr - 1) / dt:.0f} pairs/s, {1e3 * dt / nb:.3f} ms per batch; inside calls: "
+              + ", ".join(f"{k} {1e3 * v / nb:.3f}" for k, v in acc.items())
+              + f"; python between calls {1e3 * (dt - sum(acc.values())) / nb:.3f}", flush=True)
