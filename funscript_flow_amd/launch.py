@@ -52,11 +52,13 @@ def spawn_ranks(script, argv, n, out=None, err=None, grace_s=10.0, poll_s=0.05):
 
     def relay(p, dst):
         for line in iter(p.stdout.readline, b""):
+            if dst is None:
+                continue                      # our own reader went away: keep draining so that the rank never blocks on its pipe
             try:
                 dst.write(line.decode("utf-8", "replace"))
                 dst.flush()
             except (BrokenPipeError, ValueError):
-                break
+                dst = None
 
     threads = [threading.Thread(target=relay, args=(p, out if r == 0 else err), daemon=True) for r, p in enumerate(procs)]
     for t in threads:
