@@ -315,12 +315,20 @@ def verify(runner, frames, W, H, B, seed, ctx):
     return golden_check.check_batch(gold, frames, recs, dots, lambda j: ctx.download_flow(slots[j]))
 
 
+CHUNK_FRAMES = 3000   # the reference's default chunk: params["batch_size"] frames are decoded, paired and processed together (FF:2647, FF:1145-1153)
+
+
 def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None, pinned=False):
     """Host frames -> per-pair scalars through pipeline.PairEngine: every frame crosses PCIe once, on the copy stream,
     overlapped with the previous batches' kernels.  pinned = False: pageable ndarrays (what cv2.VideoCapture.read hands
     Python, FF:178), copied into the context's pinned staging first; pinned = True: the frames already lie in page-locked
     memory of the context (Context.pinned_frames = ffl_host_alloc, where prefetch.PrefetchRing makes the decoder write
-    them), so the H2D transfer starts straight out of them -- no staging copy."""
+    them), so the H2D transfer starts straight out of them -- no staging copy.
+
+    The timed unit is ONE chunk of n_frames frames from a cold pipeline, as process_video runs it (FF:1187-1242): the upload
+    of the chunk's first batch has nothing to hide behind (3.7 ms for 33 BGR frames at 1080p), so a short chunk reads low --
+    8 batches: 0.87x the resident rate from BGR, 94 batches (the reference's 3000-frame chunk): 0.98x
+    (profiles/r04_pcie_chunk_length.txt)."""
     from funscript_flow_amd import _capi, pipeline
     from funscript_flow_amd.synth import gray_to_bgr, sine_translate_frames
     if base is None:
@@ -331,10 +339,13 @@ def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None, pinned=False
     with _capi.Context(W, H, device=device, max_batch=B, frame_slots=pipeline.min_frame_slots(B, 2),
                        flow_slots=pipeline.min_flow_slots(B, 2)) as ctx:      # room for two batches queued ahead
         if pinned:
-            store = ctx.pinned_frames(n_frames, 3 if bgr else 1)
-            for i in range(n_frames):
+            # a ring of page-locked frames, a multiple of the clip's period long (so that entry i % S holds frame i's
+            # pixels): the frames of a batch lie back to back in it except where the ring wraps (one staged call per S frames)
+            S = min(n_frames, len(base) * max(1, (8 * B + len(base)) // len(base)))
+            store = ctx.pinned_frames(S, 3 if bgr else 1)
+            for i in range(S):
                 store[i] = base[i % len(base)]          # the "decoder" writes into page-locked memory, outside the timed region
-            frames = [store[i] for i in range(n_frames)]
+            frames = [store[i % S] for i in range(n_frames)]
         else:
             frames = [base[i % len(base)] for i in range(n_frames)]
         eng = pipeline.PairEngine(ctx)
@@ -344,7 +355,7 @@ def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None, pinned=False
         dt = time.perf_counter() - t0
         frames = store = None
     n = n_frames - 1
-    return {"value": n / dt, "unit": "pairs/s", "pairs": n,
+    return {"value": n / dt, "unit": "pairs/s", "pairs": n, "chunk_frames": n_frames,
             "input": ("BGR" if bgr else "gray") + (" uint8 frames in page-locked host memory (ffl_host_alloc), no staging copy" if pinned
                                                    else " uint8 pageable ndarrays, staged through pinned memory"),
             "h2d_GBps": n / dt * W * H * (3 if bgr else 1) / 1e9, "pairs_per_batch": B}
@@ -748,12 +759,13 @@ def main():
                                               "note": "one batch at a time, host waits between batches: class times are those of each kernel running alone"}
             # (2) PCIe-inclusive: host frames -> scalars (never `value`)
             _capi.set_option("lanes", 2)
-            nfr = 8 * B + 1
+            nfr = CHUNK_FRAMES
             pbase = frames if (len(frames) >= 17 and not args.independent and args.zoom == 0.0) else None
             out["pcie_inclusive"] = {"gray": pcie_inclusive(W, H, B, local_rank, seed, nfr, False, pbase),
                                      "bgr": pcie_inclusive(W, H, B, local_rank, seed, nfr, True, pbase),
                                      "bgr_pinned": pcie_inclusive(W, H, B, local_rank, seed, nfr, True, pbase, pinned=True),
-                                     "note": "pipeline.PairEngine, 2 compute lanes; gray / bgr: pageable ndarrays copied into "
+                                     "note": "one chunk of 3000 frames (the reference's default chunk, FF:2647) from a cold pipeline; "
+                                             "pipeline.PairEngine, 2 compute lanes; gray / bgr: pageable ndarrays copied into "
                                              "pinned staging by the library; bgr_pinned: frames already in ffl_host_alloc memory "
                                              "(the prefetch ring's zero-copy path)"}
             for k in ("gray", "bgr", "bgr_pinned"):
@@ -778,7 +790,7 @@ def main():
                                       "compute_lanes": 2, "graphs": sgraphs,
                                       "checked": schk[0], "check_detail": schk[1]}
                 _capi.set_option("lanes", 2)
-                out["small_image"]["pcie_inclusive_gray"] = pcie_inclusive(256, 256, SB, local_rank, 1, 8 * SB + 1, False, sfr)
+                out["small_image"]["pcie_inclusive_gray"] = pcie_inclusive(256, 256, SB, local_rank, 1, CHUNK_FRAMES, False, sfr)
                 _capi.set_option("lanes", 1)
                 # the dominant kernel's own roofline at this size: a short pass with HIP events (eager launches, one lane)
                 edt, eprof, _, _, _, _, ectx = resident_pass(256, 256, SB, 10, 2, local_rank, 1, [DOMINANT], frames=sfr)

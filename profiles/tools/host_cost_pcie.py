@@ -7,9 +7,13 @@ from funscript_flow_amd import _capi, pipeline
 from funscript_flow_amd.synth import sine_translate_frames
 
 W, H, B, lanes = (int(v) for v in (sys.argv[1:5] + ["256", "256", "256", "2"][len(sys.argv) - 1:]))
+MODE = os.environ.get("MODE", "gray")      # gray | bgr | bgr_pinned
 _capi.set_option("lanes", lanes)
 base = sine_translate_frames(17, W, H, seed=1)
-nfr = 8 * B + 1
+nfr = int(os.environ.get('BATCHES', '8')) * B + 1
+if MODE != "gray":
+    from funscript_flow_amd.synth import gray_to_bgr
+    base = gray_to_bgr(base)
 frames = [base[i % 17] for i in range(nfr)]
 acc = {}
 
@@ -25,10 +29,16 @@ def timed(obj, name):
     setattr(obj, name, g)
 
 
-with _capi.Context(W, H, max_batch=B, frame_slots=pipeline.min_frame_slots(B, 2), flow_slots=pipeline.min_flow_slots(B, 2)) as ctx:
+DEPTH = int(os.environ.get("DEPTH", "2"))
+with _capi.Context(W, H, max_batch=B, frame_slots=pipeline.min_frame_slots(B, DEPTH), flow_slots=pipeline.min_flow_slots(B, DEPTH)) as ctx:
     for n in ("upload_frames", "flow_pairs", "pass1_results", "radial"):
         timed(ctx, n)
-    eng = pipeline.PairEngine(ctx)
+    if MODE == "bgr_pinned":
+        store = ctx.pinned_frames(nfr, 3)
+        for i in range(nfr):
+            store[i] = base[i % 17]
+        frames = [store[i] for i in range(nfr)]
+    eng = pipeline.PairEngine(ctx, depth=DEPTH)
     eng.process_chunk(frames[:2 * B + 1])
     for rep in range(3):
         acc.clear()
@@ -36,6 +46,6 @@ with _capi.Context(W, H, max_batch=B, frame_slots=pipeline.min_frame_slots(B, 2)
         eng.process_chunk(frames)
         dt = time.perf_counter() - t0
         nb = (nfr - 1) / B
-        print(f"{W}x{H} B={B} lanes={lanes}: {(nfr - 1) / dt:.0f} pairs/s, {1e3 * dt / nb:.3f} ms per batch; inside calls: "
+        print(f"{MODE} depth {DEPTH} {W}x{H} B={B} lanes={lanes}: {(nfr - 1) / dt:.0f} pairs/s, {1e3 * dt / nb:.3f} ms per batch; inside calls: "
               + ", ".join(f"{k} {1e3 * v / nb:.3f}" for k, v in acc.items())
               + f"; python between calls {1e3 * (dt - sum(acc.values())) / nb:.3f}", flush=True)
