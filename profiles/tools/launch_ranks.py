@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Start N ranks of a script with the torch.distributed environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), without
+"""SUPERSEDED in round 4 by funscript_flow_amd/launch.py: `python bench.py --gpus N` now spawns its own ranks, relays rank 0's
+JSON line and stops the others on the first failure.  Kept because the round-3 rehearsal records name it.
+
+Start N ranks of a script with the torch.distributed environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), without
 torch.distributed.run: the launcher itself then never opens the GPU, so a 1-GPU rehearsal box (at most 6 processes may
 have the card open) can take 6 ranks.  Exit code = the first non-zero rank exit code.
 
