@@ -117,11 +117,15 @@ def estimate_bytes(width, height, frame_slots, flow_slots, max_batch):
 
 
 def _iarr(v):
-    return (C.c_int * len(v))(*[int(x) for x in v])
+    """int array argument: a C int pointer plus the object that keeps the memory alive (numpy does the conversion of a list
+    or an array in C; element-by-element ctypes construction cost 30 us per 256 entries, three times per batch)"""
+    a = np.ascontiguousarray(v, dtype=np.intc)
+    return a.ctypes.data_as(C.POINTER(C.c_int)), a
 
 
 def _darr(v):
-    return (C.c_double * len(v))(*[float(x) for x in v])
+    a = np.ascontiguousarray(v, dtype=np.float64)
+    return a.ctypes.data_as(C.POINTER(C.c_double)), a
 
 
 class Context:
@@ -208,7 +212,10 @@ class Context:
 
     def flow_pairs(self, fslot0, fslot1, flow_slots, pov_mode=False):
         n = len(flow_slots)
-        self._chk(self.L.ffl_flow_pairs(self._h, n, _iarr(fslot0), _iarr(fslot1), _iarr(flow_slots), int(bool(pov_mode))))
+        (p0, k0), (p1, k1), (ps, ks) = _iarr(fslot0), _iarr(fslot1), _iarr(flow_slots)
+        if len(k0) != n or len(k1) != n:
+            raise FFLError("flow_pairs: the three slot lists must have one entry per pair")
+        self._chk(self.L.ffl_flow_pairs(self._h, n, p0, p1, ps, int(bool(pov_mode))))
 
     def submit_pair(self, slot, prev, nxt, pov_mode=False):
         prev, nxt = np.ascontiguousarray(prev), np.ascontiguousarray(nxt)
@@ -226,18 +233,22 @@ class Context:
     def pass1_results(self, flow_slots, cut_threshold=7.0):
         """ffl_pass1_results: the records of many slots with one call (list of pass1_result tuples)."""
         n = len(flow_slots)
-        x, y, c = (C.c_int32 * n)(), (C.c_int32 * n)(), (C.c_int * n)()
-        v, mm = (C.c_float * n)(), (C.c_float * n)()
-        self._chk(self.L.ffl_pass1_results(self._h, n, _iarr(flow_slots), float(cut_threshold), x, y, v, mm, c))
-        return [(x[i], y[i], np.float32(v[i]), np.float32(mm[i]), bool(c[i])) for i in range(n)]
+        x, y, c = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(n, np.intc)
+        v, mm = np.empty(n, np.float32), np.empty(n, np.float32)
+        i32, f32 = C.POINTER(C.c_int32), C.POINTER(C.c_float)
+        ps, ks = _iarr(flow_slots)
+        self._chk(self.L.ffl_pass1_results(self._h, n, ps, float(cut_threshold), x.ctypes.data_as(i32), y.ctypes.data_as(i32),
+                                           v.ctypes.data_as(f32), mm.ctypes.data_as(f32), c.ctypes.data_as(C.POINTER(C.c_int))))
+        return list(zip(x.tolist(), y.tolist(), list(v), list(mm), (c != 0).tolist()))
 
     def radial(self, flow_slots, centers, is_cut, pov_mode=False):
         n = len(flow_slots)
-        out = (C.c_double * n)()
-        self._chk(self.L.ffl_radial(self._h, n, _iarr(flow_slots), _darr([c[0] for c in centers]),
-                                    _darr([c[1] for c in centers]), _iarr([int(bool(c)) for c in is_cut]),
-                                    int(bool(pov_mode)), out))
-        return [float(v) for v in out]
+        out = np.empty(n, np.float64)
+        cen = np.asarray(centers, np.float64).reshape(n, 2)
+        (ps, ks), (px, kx), (py, ky) = _iarr(flow_slots), _darr(cen[:, 0]), _darr(cen[:, 1])
+        pc, kc = _iarr(np.asarray(is_cut, bool))
+        self._chk(self.L.ffl_radial(self._h, n, ps, px, py, pc, int(bool(pov_mode)), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out.tolist()
 
     def download_frame(self, fslot):
         out = np.empty((self.height, self.width), np.uint8)

@@ -206,6 +206,8 @@ struct ffl_ctx {
     unsigned up_next = 0;
     std::vector<hipEvent_t> ev_last_use;  // [frame slot * n_lanes + lane]: handle of the last batch event, or null
     std::vector<char> frame_valid;
+    std::vector<int> u_of_fslot;      // scratch of run_batch: frame slot -> index among the batch's unique frames (-1 outside)
+    std::vector<char> slot_mark;      // scratch of check_pairs: flow slot already named in this batch
     // ffl_upload_frames_raw: decoded source frames pass through a small ring of pinned + device buffers
     // (grown on demand to the largest source seen); `ev` = the frame's k_frontend has consumed the buffer
     struct RawBuf {
@@ -453,6 +455,22 @@ static void prof_collect(ffl_ctx *c) {
     c->prof_last_end = nullptr;
 }
 
+// hipStreamWaitEvent for every DISTINCT event of a list: the 257 frames of a 256-pair batch share one or two upload events and
+// its 256 recycled flow slots one or two batch events, and a wait call costs ~0.5 us each (0.25 ms per 256-pair batch).
+struct WaitOnce {
+    hipStream_t st;
+    hipEvent_t seen[8];
+    int n = 0;
+    explicit WaitOnce(hipStream_t s) : st(s) {}
+    hipError_t operator()(hipEvent_t e) {
+        if (!e) return hipSuccess;
+        for (int k = 0; k < n; k++)
+            if (seen[k] == e) return hipSuccess;
+        if (n < 8) seen[n++] = e;
+        return hipStreamWaitEvent(st, e, 0);
+    }
+};
+
 // ---- API -----------------------------------------------------------------------------------------
 extern "C" {
 
@@ -634,6 +652,8 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     c->ev_uploaded.assign(n_frame_slots, nullptr);
     c->ev_last_use.assign((size_t)n_frame_slots * num_lanes, nullptr);  // handles into the lanes' rings
     c->frame_valid.assign(n_frame_slots, 0);
+    c->u_of_fslot.assign(n_frame_slots, -1);
+    c->slot_mark.assign(n_flow_slots, 0);
     for (auto &e : c->up_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : c->post_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     c->ev_slot_done.assign(n_flow_slots, nullptr);                        // handles, set when a slot is queued
@@ -767,11 +787,9 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
         // the device copies of these slots may still be read by batches queued on any lane -- looked up HERE, right before
         // the transfer is queued: the lock was dropped for the staging copies, and a batch another thread queued meanwhile
         // must be ordered ahead of the transfer that overwrites its frame
+        WaitOnce wait_copy(c->s_copy);
         for (int i = i0; i < i1; i++)
-            for (size_t l = 0; l < c->lanes.size(); l++) {
-                hipEvent_t e = c->ev_last_use[(size_t)(first + i) * c->lanes.size() + l];
-                if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
-            }
+            for (size_t l = 0; l < c->lanes.size(); l++) HIPCHK(c, wait_copy(c->ev_last_use[(size_t)(first + i) * c->lanes.size() + l]));
         uint8_t *gray = c->d_gray + (size_t)(first + i0) * N;
         const uint8_t *src = (direct ? frames[0] : stage0) + (size_t)i0 * fbytes;
         const int m = i1 - i0;
@@ -1096,11 +1114,13 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     if (L.tab_used[e]) HIPCHK(c, hipEventSynchronize(L.ev_ring[e]));
     BatchTab &T = L.h_tab[e];
     int nU = 0;
-    auto uidx = [&](int fs) {
-        for (int i = 0; i < nU; i++)
-            if (T.ut.fslot[i] == fs) return i;
-        T.ut.fslot[nU] = fs;
-        return nU++;
+    auto uidx = [&](int fs) {  // O(1) through the context's scratch map (a linear search cost 65 k compares per 256-pair batch)
+        int &u = c->u_of_fslot[fs];
+        if (u < 0) {
+            T.ut.fslot[nU] = fs;
+            u = nU++;
+        }
+        return u;
     };
     for (int i = 0; i < n; i++) {
         T.pt.u0[i] = uidx(f0[i]);
@@ -1116,10 +1136,12 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     }
     for (int k = c->levels + 1; k < FFL_MAX_LEVELS; k++)
         for (int i = 0; i < n; i++) T.pt.flow[k][i] = nullptr;
-    for (int i = 0; i < nU; i++) HIPCHK(c, hipStreamWaitEvent(st, c->ev_uploaded[T.ut.fslot[i]], 0));
+    for (int i = 0; i < nU; i++) c->u_of_fslot[T.ut.fslot[i]] = -1;  // the scratch map goes back to "empty"
+    WaitOnce wait(st);
+    for (int i = 0; i < nU; i++) HIPCHK(c, wait(c->ev_uploaded[T.ut.fslot[i]]));
     // a flow slot being recycled may still be read by the batch (other lane) or pass 2 that used it last
     for (int i = 0; i < n; i++)
-        if (c->slot_state[slots[i]]) HIPCHK(c, hipStreamWaitEvent(st, c->ev_slot_done[slots[i]], 0));
+        if (c->slot_state[slots[i]]) HIPCHK(c, wait(c->ev_slot_done[slots[i]]));
     // stream order puts this copy behind the lane's previous batch, which reads the same device table
     HIPCHK(c, hipMemcpyAsync(L.d_tab, &T, sizeof(BatchTab), hipMemcpyHostToDevice, st));
     L.tab_used[e] = true;
@@ -1203,9 +1225,14 @@ static int check_pairs(ffl_ctx *c, int n, const int *f0, const int *f1, const in
         if (!c->frame_valid[f0[i]] || !c->frame_valid[f1[i]])
             return set_err(c, FFL_ERR_STATE, "pair %d: frame slot was never uploaded", i);
         if (slots[i] < 0 || slots[i] >= c->n_slots) return set_err(c, FFL_ERR_INVALID, "pair %d: flow slot out of range", i);
-        for (int j = 0; j < i; j++)
-            if (slots[j] == slots[i]) return set_err(c, FFL_ERR_INVALID, "flow slot %d used twice in one batch", slots[i]);
     }
+    int dup = -1;  // O(n) through the context's scratch marks
+    for (int i = 0; i < n; i++) {
+        if (c->slot_mark[slots[i]] && dup < 0) dup = slots[i];
+        c->slot_mark[slots[i]] = 1;
+    }
+    for (int i = 0; i < n; i++) c->slot_mark[slots[i]] = 0;
+    if (dup >= 0) return set_err(c, FFL_ERR_INVALID, "flow slot %d used twice in one batch", dup);
     return FFL_OK;
 }
 
@@ -1285,6 +1312,7 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
     if (n < 1 || n > FFL_MAXB || !slots || !cx || !cy || !out) return set_err(c, FFL_ERR_INVALID, "ffl_radial: bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     RadialTab &rt = *c->h_rtab;  // the previous call waited for s_post, so the pinned copy is free
+    WaitOnce wait_post(c->s_post);
     int m = 0;
     int map[FFL_MAXB];
     for (int i = 0; i < n; i++) {
@@ -1294,7 +1322,7 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
             out[i] = 0.0;
             continue;
         }
-        HIPCHK(c, hipStreamWaitEvent(c->s_post, c->ev_slot_done[slots[i]], 0));
+        HIPCHK(c, wait_post(c->ev_slot_done[slots[i]]));
         rt.flow[m] = c->d_flow + (size_t)slots[i] * 2 * c->N;
         rt.cx[m] = cx[i];
         rt.cy[m] = cy[i];
