@@ -4,6 +4,8 @@ import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch  # noqa: F401
 from funscript_flow_amd import _capi, pipeline
+if os.environ.get("FFL_LIB"):
+    _capi.LIB_PATH = os.path.abspath(os.environ["FFL_LIB"])
 from funscript_flow_amd.synth import sine_translate_frames
 
 W, H, B, lanes = (int(v) for v in (sys.argv[1:5] + ["256", "256", "256", "2"][len(sys.argv) - 1:]))
@@ -30,7 +32,9 @@ def timed(obj, name):
 
 
 DEPTH = int(os.environ.get("DEPTH", "2"))
-with _capi.Context(W, H, max_batch=B, frame_slots=pipeline.min_frame_slots(B, DEPTH), flow_slots=pipeline.min_flow_slots(B, DEPTH)) as ctx:
+CTXDEPTH = int(os.environ.get("CTXDEPTH", str(DEPTH)))
+FS = int(os.environ.get("FRAME_SLOTS", str(pipeline.min_frame_slots(B, CTXDEPTH))))
+with _capi.Context(W, H, max_batch=B, frame_slots=FS, flow_slots=pipeline.min_flow_slots(B, CTXDEPTH)) as ctx:
     for n in ("upload_frames", "flow_pairs", "pass1_results", "radial"):
         timed(ctx, n)
     if MODE == "bgr_pinned":
@@ -46,6 +50,6 @@ with _capi.Context(W, H, max_batch=B, frame_slots=pipeline.min_frame_slots(B, DE
         eng.process_chunk(frames)
         dt = time.perf_counter() - t0
         nb = (nfr - 1) / B
-        print(f"{MODE} depth {DEPTH} {W}x{H} B={B} lanes={lanes}: {(nfr - 1) / dt:.0f} pairs/s, {1e3 * dt / nb:.3f} ms per batch; inside calls: "
+        print(f"{MODE} depth {DEPTH} ctx {CTXDEPTH} fs {FS} {W}x{H} B={B} lanes={lanes}: {(nfr - 1) / dt:.0f} pairs/s, {1e3 * dt / nb:.3f} ms per batch; inside calls: "
               + ", ".join(f"{k} {1e3 * v / nb:.3f}" for k, v in acc.items())
               + f"; python between calls {1e3 * (dt - sum(acc.values())) / nb:.3f}", flush=True)
