@@ -336,9 +336,8 @@ def pcie_inclusive(W, H, B, device, seed, n_frames, bgr, base=None, pinned=False
     base = base[:17]                                  # one period of the clip, cycled
     if bgr:
         base = gray_to_bgr(base)
-    qd = 3 if W * H <= 640 * 360 else 2            # batches queued ahead: PairEngine's default for the frame size
-    with _capi.Context(W, H, device=device, max_batch=B, frame_slots=pipeline.min_frame_slots(B, qd),
-                       flow_slots=pipeline.min_flow_slots(B, qd)) as ctx:
+    with _capi.Context(W, H, device=device, max_batch=B, frame_slots=pipeline.min_frame_slots(B, 2),
+                       flow_slots=pipeline.min_flow_slots(B, 2)) as ctx:      # room for two batches queued ahead
         if pinned:
             # a ring of page-locked frames, a multiple of the clip's period long (so that entry i % S holds frame i's
             # pixels): the frames of a batch lie back to back in it except where the ring wraps (one staged call per S frames)
@@ -778,8 +777,7 @@ def main():
                 # two compute lanes (the library's default): small levels are latency-bound, a second batch in flight
                 # fills the device (+7 % over one lane at this size); no per-kernel events are taken in this pass
                 _capi.set_option("lanes", 2)
-                # three batches queued ahead: with two lanes two of them run, and one more is waiting when the host comes back
-                sdt, sprof, srun, sfr, slv, sU, sctx = resident_pass(256, 256, SB, 30, 5, local_rank, 1, False, depth=3)
+                sdt, sprof, srun, sfr, slv, sU, sctx = resident_pass(256, 256, SB, 30, 5, local_rank, 1, False)
                 schk = verify(srun, sfr, 256, 256, SB, 1, sctx)
                 sgraphs = sctx.graph_stats()
                 sctx.close()

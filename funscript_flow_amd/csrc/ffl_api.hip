@@ -43,6 +43,48 @@ static thread_local std::string g_create_error = "";
 static FflOptions g_opts;
 static std::mutex g_opt_mu;
 
+// Events come from small rings, one per stream (a lane's "batch finished" events, the upload events of stream `copy`, the
+// events of stream `post`), and what the slot tables hold are REFERENCES to ring entries: (ring, ticket).  An entry is
+// recorded again once the ring has gone round.  A reference that outlived its entry must not be waited on any more: the
+// event it names now stands for a much LATER operation of that stream -- possibly one that is still running -- and waiting
+// for it serialises things that have nothing to do with each other.  (Rounds 1-3 kept bare hipEvent_t handles.  Harmless
+// for correctness, since "later work of the same stream" is a conservative wait, but not for speed: with 131 or 132 frame
+// slots at B = 32 a slot's last-use handle of the OTHER lane went 33 batches without being refreshed, and from the moment
+// the lanes' 16-entry rings wrapped every upload waited for the batch in flight: 5.1 -> 8.9 ms per batch from batch 33 on,
+// profiles/r04_pcie_chunk_length.txt.)  So: take() waits on the host for the entry it is about to hand out again -- that
+// operation is `size` operations old and practically always long finished -- which makes "stale" imply "completed", and
+// EvRef::get() answers nullptr for a stale reference: nothing to wait for.
+struct EvRing {
+    std::vector<hipEvent_t> ev;
+    unsigned long long next = 0;  // tickets handed out so far
+    hipError_t create(int n) {
+        ev.assign(n, nullptr);
+        for (auto &e : ev) {
+            hipError_t r = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+            if (r != hipSuccess) return r;
+        }
+        return hipSuccess;
+    }
+    void destroy() {
+        for (auto e : ev)
+            if (e) hipEventDestroy(e);
+        ev.clear();
+    }
+    // the entry the next take() hands out: its previous operation (`size` operations ago) must be over
+    hipError_t settle_next() { return next >= ev.size() ? hipEventSynchronize(ev[next % ev.size()]) : hipSuccess; }
+    hipEvent_t take(unsigned long long *ticket) {
+        *ticket = next;
+        return ev[next++ % ev.size()];
+    }
+};
+struct EvRef {
+    const EvRing *ring = nullptr;
+    unsigned long long ticket = 0;
+    // the event to wait on, or nullptr when there is nothing (never set, or the entry has been handed out again: completed)
+    hipEvent_t get() const { return (ring && ring->next - ticket <= ring->ev.size()) ? ring->ev[ticket % ring->ev.size()] : nullptr; }
+};
+static inline EvRef ev_latest(const EvRing &r) { return r.next ? EvRef{&r, r.next - 1} : EvRef{}; }
+
 struct ProfRec {
     int cls;
     hipEvent_t a, b;
@@ -177,16 +219,13 @@ struct ffl_ctx {
         size_t i_off[8] = {0};  // float offset of level k inside d_I
         size_t t_off[8] = {0};  // float offset of level k inside d_T (pyramid horizontal-pass buffer)
         float *d_T = nullptr;
-        hipEvent_t ev_ring[FFL_EV_RING] = {nullptr};  // one "batch finished" event per batch, recycled
-        unsigned ring_next = 0;
-        hipEvent_t ev_done = nullptr;  // handle into ev_ring: the lane's latest batch
+        EvRing ring;  // one "batch finished" event per batch (FFL_EV_RING entries)
         size_t r_off[8] = {0};  // float offset of level k inside d_R
         float *d_I = nullptr, *d_R = nullptr, *d_M[2] = {nullptr, nullptr}, *d_flowA = nullptr, *d_flowB = nullptr;
         unsigned long long *d_pkey = nullptr;
         double *d_psum = nullptr;
-        // per-batch index tables: device copy + a ring of pinned host copies (entry e belongs to ev_ring[e])
+        // per-batch index tables: device copy + a ring of pinned host copies (entry e belongs to ring entry e)
         BatchTab *d_tab = nullptr, *h_tab = nullptr;
-        bool tab_used[FFL_EV_RING] = {false};
         struct GraphEntry {
             int n, nU, pov, epoch;
             hipGraph_t graph;
@@ -201,10 +240,9 @@ struct ffl_ctx {
     uint8_t *d_bgr = nullptr;         // [n_fslots][3N] staging for 3-channel uploads
     uint8_t *h_stage_gray = nullptr;  // pinned [n_fslots][N]   (separate, so that runs of slots are contiguous)
     uint8_t *h_stage_bgr = nullptr;   // pinned [n_fslots][3N]
-    std::vector<hipEvent_t> ev_uploaded;  // handles into up_ring (one event per upload call), or null
-    hipEvent_t up_ring[2 * FFL_EV_RING] = {nullptr};
-    unsigned up_next = 0;
-    std::vector<hipEvent_t> ev_last_use;  // [frame slot * n_lanes + lane]: handle of the last batch event, or null
+    std::vector<EvRef> ev_uploaded;  // per frame slot: the upload call that filled it (one event per call, up_ring)
+    EvRing up_ring;                  // 2 * FFL_EV_RING entries
+    std::vector<EvRef> ev_last_use;  // [frame slot * n_lanes + lane]: the last batch of that lane that read the slot
     std::vector<char> frame_valid;
     std::vector<int> u_of_fslot;      // scratch of run_batch: frame slot -> index among the batch's unique frames (-1 outside)
     std::vector<char> slot_mark;      // scratch of check_pairs: flow slot already named in this batch
@@ -218,15 +256,14 @@ struct ffl_ctx {
     };
     RawBuf raw[FFL_RAW_RING];
     unsigned raw_next = 0;
-    hipEvent_t post_ring[FFL_EV_RING] = {nullptr};  // events of ffl_upload_flow and ffl_radial (s_post); a ring, so a handle an old slot still holds only ever points to later work of that stream
-    unsigned post_next = 0;
+    EvRing post_ring;  // events of ffl_upload_flow and ffl_radial (stream `post`), FFL_EV_RING entries
     // flow slots
     float *d_flow = nullptr;          // [n_slots][2N]
     // Result records live in pinned, device-mapped host memory: the reduction kernels store their
     // 24-byte record straight into it (visible after the slot's event), so no D2H copies are queued.
     Pass1Result *h_res = nullptr;     // pinned [n_slots]
     Pass1Result *d_res = nullptr;     // device alias of h_res
-    std::vector<hipEvent_t> ev_slot_done;
+    std::vector<EvRef> ev_slot_done;  // per flow slot: the batch (a lane's ring) or pass-2 / flow-upload call (post_ring) that used it last
     std::vector<char> slot_state;     // 0 empty, 1 queued/ready
     std::vector<char> slot_pov;
     RadialTab *d_rtab = nullptr, *h_rtab = nullptr;    // pass-2 table (s_post; ffl_radial waits for the stream, so one copy)
@@ -507,10 +544,8 @@ void ffl_destroy(ffl_ctx *c) {
     c->pool.shutdown();
     for (auto e : c->prof_pool) hipEventDestroy(e);
     for (auto &hb : c->host_bufs) hipHostFree(hb.first);
-    for (auto e : c->up_ring)
-        if (e) hipEventDestroy(e);
-    for (auto e : c->post_ring)
-        if (e) hipEventDestroy(e);
+    c->up_ring.destroy();
+    c->post_ring.destroy();
     hipFree(c->d_gray); hipFree(c->d_bgr); hipHostFree(c->h_stage_gray); hipHostFree(c->h_stage_bgr);
     for (auto &rb : c->raw) {
         hipFree(rb.d);
@@ -527,8 +562,7 @@ void ffl_destroy(ffl_ctx *c) {
         }
         for (auto e : L.ev_R)
             if (e) hipEventDestroy(e);
-        for (auto e : L.ev_ring)
-            if (e) hipEventDestroy(e);
+        L.ring.destroy();
         if (L.ev_fork) hipEventDestroy(L.ev_fork);
         for (auto s : L.st_aux)
             if (s) hipStreamDestroy(s);
@@ -606,7 +640,7 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
         // onto a few hardware queues, and idle extra streams make the latency-critical `post` / `copy`
         // streams share a queue with a compute lane (pass 2 then waits behind whole queued batches)
         CCHK(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming));
-        for (auto &e : L.ev_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        CCHK(L.ring.create(FFL_EV_RING));
         size_t r_total = 0, i_total = 0, t_total = 0;
         for (int k = 0; k <= c->levels; k++) {
             CCHK(hipEventCreateWithFlags(&L.ev_R[k], hipEventDisableTiming));
@@ -649,14 +683,14 @@ int ffl_create(int device, int width, int height, int n_frame_slots, int n_flow_
     CCHK(hipMalloc(&c->d_ppkey, sizeof(unsigned long long) * c->p1_blocks));
     CCHK(hipHostMalloc(&c->h_radial, sizeof(double) * FFL_MAXB, hipHostMallocMapped));
     CCHK(hipHostGetDevicePointer((void **)&c->d_radial, c->h_radial, 0));
-    c->ev_uploaded.assign(n_frame_slots, nullptr);
-    c->ev_last_use.assign((size_t)n_frame_slots * num_lanes, nullptr);  // handles into the lanes' rings
+    c->ev_uploaded.assign(n_frame_slots, EvRef{});
+    c->ev_last_use.assign((size_t)n_frame_slots * num_lanes, EvRef{});  // references into the lanes' rings
     c->frame_valid.assign(n_frame_slots, 0);
     c->u_of_fslot.assign(n_frame_slots, -1);
     c->slot_mark.assign(n_flow_slots, 0);
-    for (auto &e : c->up_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    for (auto &e : c->post_ring) CCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-    c->ev_slot_done.assign(n_flow_slots, nullptr);                        // handles, set when a slot is queued
+    CCHK(c->up_ring.create(2 * FFL_EV_RING));
+    CCHK(c->post_ring.create(FFL_EV_RING));
+    c->ev_slot_done.assign(n_flow_slots, EvRef{});                        // set when a slot is queued
     c->slot_state.assign(n_flow_slots, 0);
     c->slot_pov.assign(n_flow_slots, 0);
 #undef CCHK
@@ -789,7 +823,7 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
         // must be ordered ahead of the transfer that overwrites its frame
         WaitOnce wait_copy(c->s_copy);
         for (int i = i0; i < i1; i++)
-            for (size_t l = 0; l < c->lanes.size(); l++) HIPCHK(c, wait_copy(c->ev_last_use[(size_t)(first + i) * c->lanes.size() + l]));
+            for (size_t l = 0; l < c->lanes.size(); l++) HIPCHK(c, wait_copy(c->ev_last_use[(size_t)(first + i) * c->lanes.size() + l].get()));
         uint8_t *gray = c->d_gray + (size_t)(first + i0) * N;
         const uint8_t *src = (direct ? frames[0] : stage0) + (size_t)i0 * fbytes;
         const int m = i1 - i0;
@@ -823,7 +857,7 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
             // staging copy run WITHOUT the context lock (up_mu keeps other uploaders out of the staging areas and the pool)
             std::vector<hipEvent_t> prev;
             for (int k = i; k < j; k++) {
-                hipEvent_t e = c->ev_uploaded[first + k];
+                hipEvent_t e = c->ev_uploaded[first + k].get();
                 if (e && (prev.empty() || prev.back() != e)) prev.push_back(e);
             }
             lk.unlock();
@@ -838,10 +872,11 @@ int ffl_upload_frames(ffl_ctx *c, int first, int n, const uint8_t *const *frames
             i = j;
         }
     }
-    hipEvent_t ev = c->up_ring[c->up_next++ % (2 * FFL_EV_RING)];
-    HIPCHK(c, hipEventRecord(ev, c->s_copy));
+    HIPCHK(c, c->up_ring.settle_next());  // 32 upload calls old: over long ago
+    EvRef ref{&c->up_ring, 0};
+    HIPCHK(c, hipEventRecord(c->up_ring.take(&ref.ticket), c->s_copy));
     for (int i = 0; i < n; i++) {
-        c->ev_uploaded[first + i] = ev;
+        c->ev_uploaded[first + i] = ref;
         c->frame_valid[first + i] = 1;
     }
     return FFL_OK;
@@ -907,7 +942,7 @@ int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *fr
             lk.lock();
         }
         for (size_t l = 0; l < c->lanes.size(); l++) {  // batches still reading the slot's previous frame
-            hipEvent_t e = c->ev_last_use[(size_t)fs * c->lanes.size() + l];
+            hipEvent_t e = c->ev_last_use[(size_t)fs * c->lanes.size() + l].get();
             if (e) HIPCHK(c, hipStreamWaitEvent(c->s_copy, e, 0));
         }
         HIPCHK(c, hipMemcpyAsync(rb.d, direct ? data : rb.h, fbytes, hipMemcpyHostToDevice, c->s_copy));
@@ -918,8 +953,9 @@ int ffl_upload_frames_raw(ffl_ctx *c, int first, int n, const uint8_t *const *fr
         HIPCHK(c, hipEventRecord(rb.ev, c->s_copy));
         rb.busy = true;
     }
-    hipEvent_t ev = c->up_ring[c->up_next++ % (2 * FFL_EV_RING)];
-    HIPCHK(c, hipEventRecord(ev, c->s_copy));
+    HIPCHK(c, c->up_ring.settle_next());
+    EvRef ev{&c->up_ring, 0};
+    HIPCHK(c, hipEventRecord(c->up_ring.take(&ev.ticket), c->s_copy));
     for (int i = 0; i < n; i++) {
         // a gray upload into this slot may still be in flight out of the slot's own staging area; the new
         // handle is later on the same stream, so waiting on it covers that transfer as well
@@ -1110,8 +1146,8 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     hipStream_t st = L.st;
     const size_t N = c->N;
     // the batch's table: a pinned ring entry (its previous batch, FFL_EV_RING batches ago, must have consumed it)
-    const unsigned e = L.ring_next % FFL_EV_RING;
-    if (L.tab_used[e]) HIPCHK(c, hipEventSynchronize(L.ev_ring[e]));
+    const unsigned e = (unsigned)(L.ring.next % FFL_EV_RING);
+    HIPCHK(c, L.ring.settle_next());  // also frees the table entry: its batch, FFL_EV_RING batches ago, has consumed it
     BatchTab &T = L.h_tab[e];
     int nU = 0;
     auto uidx = [&](int fs) {  // O(1) through the context's scratch map (a linear search cost 65 k compares per 256-pair batch)
@@ -1138,13 +1174,12 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
         for (int i = 0; i < n; i++) T.pt.flow[k][i] = nullptr;
     for (int i = 0; i < nU; i++) c->u_of_fslot[T.ut.fslot[i]] = -1;  // the scratch map goes back to "empty"
     WaitOnce wait(st);
-    for (int i = 0; i < nU; i++) HIPCHK(c, wait(c->ev_uploaded[T.ut.fslot[i]]));
+    for (int i = 0; i < nU; i++) HIPCHK(c, wait(c->ev_uploaded[T.ut.fslot[i]].get()));
     // a flow slot being recycled may still be read by the batch (other lane) or pass 2 that used it last
     for (int i = 0; i < n; i++)
-        if (c->slot_state[slots[i]]) HIPCHK(c, wait(c->ev_slot_done[slots[i]]));
+        if (c->slot_state[slots[i]]) HIPCHK(c, wait(c->ev_slot_done[slots[i]].get()));
     // stream order puts this copy behind the lane's previous batch, which reads the same device table
     HIPCHK(c, hipMemcpyAsync(L.d_tab, &T, sizeof(BatchTab), hipMemcpyHostToDevice, st));
-    L.tab_used[e] = true;
 
     const bool use_graph = c->opt.use_graph && !cap && c->prof_mask == 0 && c->opt.run_ahead == 0;
     if (use_graph) {
@@ -1203,9 +1238,8 @@ static int run_batch(ffl_ctx *c, int li, int n, const int *f0, const int *f1, co
     }
     // ONE event per batch: it marks the slots' results as ready, the frames' last use and the lane's
     // work buffers as free (a ring, so handles held by older slots only ever point to later work)
-    hipEvent_t ev = L.ev_ring[L.ring_next++ % FFL_EV_RING];
-    HIPCHK(c, hipEventRecord(ev, st));
-    L.ev_done = ev;
+    EvRef ev{&L.ring, 0};
+    HIPCHK(c, hipEventRecord(L.ring.take(&ev.ticket), st));
     for (int i = 0; i < nU; i++) c->ev_last_use[(size_t)T.ut.fslot[i] * c->lanes.size() + li] = ev;
     for (int i = 0; i < n; i++) {
         c->ev_slot_done[slots[i]] = ev;
@@ -1272,9 +1306,9 @@ int ffl_pass1_result(ffl_ctx *c, int slot, float cut_threshold, int32_t *x, int3
     {
         // wait without the lock: the event handle is a ring entry that is only ever re-recorded for LATER work
         // of the same lane, so waiting on it after another thread queued more batches is still sufficient
-        hipEvent_t ev = c->ev_slot_done[slot];
+        hipEvent_t ev = c->ev_slot_done[slot].get();
         lk.unlock();
-        hipError_t e = hipEventSynchronize(ev);
+        hipError_t e = ev ? hipEventSynchronize(ev) : hipSuccess;
         lk.lock();
         HIPCHK(c, e);
     }
@@ -1322,7 +1356,7 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
             out[i] = 0.0;
             continue;
         }
-        HIPCHK(c, wait_post(c->ev_slot_done[slots[i]]));
+        HIPCHK(c, wait_post(c->ev_slot_done[slots[i]].get()));
         rt.flow[m] = c->d_flow + (size_t)slots[i] * 2 * c->N;
         rt.cx[m] = cx[i];
         rt.cy[m] = cy[i];
@@ -1338,8 +1372,9 @@ int ffl_radial(ffl_ctx *c, int n, const int *slots, const double *cx, const doub
     {
         // the slots' "last use" now includes this pass 2: the wait below runs without the context lock, so another thread
         // may queue a batch that recycles one of these slots meanwhile -- it must run behind the kernel that reads them
-        hipEvent_t ev = c->post_ring[c->post_next++ % FFL_EV_RING];
-        HIPCHK(c, hipEventRecord(ev, st));
+        HIPCHK(c, c->post_ring.settle_next());
+        EvRef ev{&c->post_ring, 0};
+        HIPCHK(c, hipEventRecord(c->post_ring.take(&ev.ticket), st));
         for (int j = 0; j < m; j++) c->ev_slot_done[slots[map[j]]] = ev;
     }
     lk.unlock();  // the wait (for the batches the slots come from, then pass 2) does not hold up uploads / submissions
@@ -1358,9 +1393,9 @@ int ffl_download_flow(ffl_ctx *c, int slot, float *dst) {
     if (!c->slot_state[slot]) return set_err(c, FFL_ERR_STATE, "flow slot %d holds no flow", slot);
     HIPCHK(c, hipSetDevice(c->device));
     {
-        hipEvent_t ev = c->ev_slot_done[slot];
+        hipEvent_t ev = c->ev_slot_done[slot].get();
         lk.unlock();
-        hipError_t e = hipEventSynchronize(ev);
+        hipError_t e = ev ? hipEventSynchronize(ev) : hipSuccess;
         lk.lock();
         HIPCHK(c, e);
     }
@@ -1376,7 +1411,7 @@ int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t st = c->s_post;
     {
-        hipEvent_t ev = c->slot_state[slot] ? c->ev_slot_done[slot] : nullptr;
+        hipEvent_t ev = c->slot_state[slot] ? c->ev_slot_done[slot].get() : nullptr;
         lk.unlock();
         hipError_t e = ev ? hipEventSynchronize(ev) : hipSuccess;
         if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1391,8 +1426,9 @@ int ffl_upload_flow(ffl_ctx *c, int slot, const float *src, int pov_mode) {
         ProfScope ps(c, FFL_K_PASS1, st);
         ffl_launch_pass1(&c->d_ptab->pt, 1, c->w, c->h, pov_mode, c->d_ppkey, c->d_rpsum, st);
     }
-    c->ev_slot_done[slot] = c->post_ring[c->post_next++ % FFL_EV_RING];
-    HIPCHK(c, hipEventRecord(c->ev_slot_done[slot], st));
+    HIPCHK(c, c->post_ring.settle_next());
+    c->ev_slot_done[slot] = EvRef{&c->post_ring, 0};
+    HIPCHK(c, hipEventRecord(c->post_ring.take(&c->ev_slot_done[slot].ticket), st));
     c->slot_state[slot] = 1;
     c->slot_pov[slot] = (char)(pov_mode != 0);
     HIPCHK(c, hipGetLastError());
@@ -1428,12 +1464,12 @@ int ffl_sync(ffl_ctx *c) {
     // lane's stream, and hipStreamSynchronize on a capturing stream fails and invalidates the capture.  Each handle is a
     // ring entry that is only ever re-recorded for LATER work of its stream, so waiting on it stays sufficient.
     std::vector<hipEvent_t> evs;
-    if (c->up_next) evs.push_back(c->up_ring[(c->up_next - 1) % (2 * FFL_EV_RING)]);
+    if (hipEvent_t e = ev_latest(c->up_ring).get()) evs.push_back(e);
     for (auto &rb : c->raw)
         if (rb.busy && rb.ev) evs.push_back(rb.ev);
     for (auto &L : c->lanes)
-        if (L.ev_done) evs.push_back(L.ev_done);
-    if (c->post_next) evs.push_back(c->post_ring[(c->post_next - 1) % FFL_EV_RING]);
+        if (hipEvent_t e = ev_latest(L.ring).get()) evs.push_back(e);
+    if (hipEvent_t e = ev_latest(c->post_ring).get()) evs.push_back(e);
     lk.unlock();
     hipError_t e = hipSuccess;
     for (auto ev : evs)

@@ -81,20 +81,16 @@ class PairEngine:
     def __init__(self, ctx, upload=None, depth=None):
         """`upload(first_slot, frames)` puts a run of frames into consecutive frame slots; the default takes
         gray (or same-size BGR) operands, frontend.DecodedUploader takes frames as decoded (any size).
-        `depth`: batches queued on the device before the oldest one's results are collected.  Default: 2 -- or 3 for
-        small frames (<= 640x360) -- when the context has the slots for it ((depth + 1)(B + 1) frame slots, (depth + 1) B
-        + 13 flow slots), else 1.  With depth 2 the upload of batch s + 2 is already queued while batch s computes, so a
-        slow transfer or a host hiccup does not idle the device.  Depth 3 pays where a batch is short against the host's
-        turn-around (256x256 B = 256: 1.4 ms per batch; with two compute lanes a third batch is then still queued behind
-        the two that run while the host collects, stages and submits: +4 % from host frames) and costs where batches are
-        long and their uploads large (1080p: -4 % from gray frames, far more from page-locked BGR:
-        profiles/r04_pcie_chunk_length.txt).  Results do not depend on it."""
+        `depth`: batches queued on the device before the oldest one's results are collected (default: 2 when the
+        context has the slots for it -- 3B + 3 frame slots, 3B + 13 flow slots -- else 1).  With depth 2 the upload of
+        batch s + 2 is already queued while batch s computes, so a slow transfer or a host hiccup does not idle the device;
+        a third batch queued ahead measures within 1 % of two at 1080p and at 256x256 (profiles/r04_pcie_chunk_length.txt).
+        Results do not depend on it."""
         self.ctx = ctx
         self.upload = upload or ctx.upload_frames
         self.B = ctx.max_batch
         if depth is None:
-            want = (3, 2) if getattr(ctx, "width", 1 << 30) * getattr(ctx, "height", 1) <= 640 * 360 else (2,)
-            depth = next((d for d in want if ctx.frame_slots >= min_frame_slots(self.B, d) and ctx.flow_slots >= min_flow_slots(self.B, d)), 1)
+            depth = 2 if (ctx.frame_slots >= min_frame_slots(self.B, 2) and ctx.flow_slots >= min_flow_slots(self.B, 2)) else 1
         self.depth = int(depth)
         if self.depth > 1 and (ctx.frame_slots < min_frame_slots(self.B, self.depth) or ctx.flow_slots < min_flow_slots(self.B, self.depth)):
             raise ValueError(f"context too small for depth {self.depth}: need frame_slots >= {min_frame_slots(self.B, self.depth)} "

@@ -42,13 +42,27 @@ with _capi.Context(W, H, max_batch=B, frame_slots=FS, flow_slots=pipeline.min_fl
         for i in range(nfr):
             store[i] = base[i % 17]
         frames = [store[i] for i in range(nfr)]
+    if os.environ.get("USE_SLOTS"):
+        ctx.frame_slots = int(os.environ["USE_SLOTS"])   # the engine's ring uses fewer slots than the context owns (placement vs ring-size test)
     eng = pipeline.PairEngine(ctx, depth=DEPTH)
     eng.process_chunk(frames[:2 * B + 1])
+    stamps = []
+    if os.environ.get("TRACE"):
+        orig = ctx.pass1_results
+
+        def traced(*a, **k):
+            r = orig(*a, **k)
+            stamps.append(time.perf_counter())
+            return r
+        ctx.pass1_results = traced
     for rep in range(3):
         acc.clear()
+        stamps.clear()
         t0 = time.perf_counter()
         eng.process_chunk(frames)
         dt = time.perf_counter() - t0
+        if stamps:
+            print("batch completion deltas ms:", " ".join(f"{1e3 * (b - a):.1f}" for a, b in zip([t0] + stamps[:-1], stamps)))
         nb = (nfr - 1) / B
         print(f"{MODE} depth {DEPTH} ctx {CTXDEPTH} fs {FS} {W}x{H} B={B} lanes={lanes}: {(nfr - 1) / dt:.0f} pairs/s, {1e3 * dt / nb:.3f} ms per batch; inside calls: "
               + ", ".join(f"{k} {1e3 * v / nb:.3f}" for k, v in acc.items())

@@ -589,3 +589,40 @@ def test_sync_from_another_thread_while_new_batch_shapes_are_captured():
             assert np.array_equal(ctx.download_flow(0), orc.farneback(fr[nmax - 1], fr[nmax]))
     finally:
         _capi.set_option("lanes", 2)
+
+
+def test_long_chunk_outlives_the_event_rings():
+    """A chunk of far more batches than the event rings have entries (16 per lane, 32 upload events), on the frame-ring
+    geometry that exposed stale event handles in round 4: 4 (B + 1) frame slots, two lanes -- a slot's last-use reference of
+    the OTHER lane then goes more than a ring's length without being refreshed.  A stale reference must count as completed
+    (never as "wait for whatever that ring entry stands for now"), and nothing about the order of uploads, batches and pass
+    2 may change: the chunk's records and scalars equal those of a one-lane context with ample slots, frames fed from
+    page-locked memory (zero-copy uploads) and from ndarrays alike, and sampled pairs equal the oracle."""
+    w, h, B, n = 96, 64, 4, 230                                       # 229 pairs = 58 batches: the lanes' rings wrap twice
+    base = sine_translate_frames(23, w, h, seed=9, amp=(2.0, 1.5), period=11, zoom=0.02)
+    frames = [base[i % 23] for i in range(n)]
+    try:
+        _capi.set_option("lanes", 1)
+        with _capi.Context(w, h, max_batch=B, frame_slots=64, flow_slots=64) as ref_ctx:
+            want_dots, want_recs = pipeline.PairEngine(ref_ctx, depth=1).process_chunk(frames)
+        _capi.set_option("lanes", 2)
+        for pinned in (False, True):
+            with _capi.Context(w, h, max_batch=B, frame_slots=4 * (B + 1), flow_slots=pipeline.min_flow_slots(B, 2)) as ctx:
+                fl = frames
+                if pinned:
+                    store = ctx.pinned_frames(n)
+                    for i in range(n):
+                        store[i] = frames[i]
+                    fl = [store[i] for i in range(n)]
+                dots, recs = pipeline.PairEngine(ctx, depth=2).process_chunk(fl)
+                assert ctx.graph_stats()["capture_failures"] == 0
+            assert np.array_equal(dots, want_dots), pinned
+            assert [tuple(r) for r in recs] == [tuple(r) for r in want_recs], pinned
+    finally:
+        _capi.set_option("lanes", 2)
+    centers = pipeline.smooth_centers([(r[0], r[1]) for r in want_recs])
+    for j in (0, 101, 228):
+        flow = orc.farneback(frames[j], frames[j + 1])
+        assert (want_recs[j][0], want_recs[j][1]) == orc.max_divergence_np(flow)[:2], j
+        ref = float(orc.radial_np(flow, centers[j], want_recs[j][4], False))
+        assert abs(want_dots[j] - ref) <= 1e-4 * max(abs(ref), 1e-3), j

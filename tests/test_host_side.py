@@ -302,11 +302,10 @@ def test_pair_engine_frame_ring_and_slot_bounds():
     eng.pass1(frames, 0, 39)
     got = [p for b in ctx.batches for p in b]
     assert [(a, b) for a, b, _ in got] == [(j, j + 1) for j in range(39)] and sum(n for _, n in ctx.uploads) == 40
-    # depth 3 where the slots allow it: same batches, every frame still uploaded once
+    # an explicit depth 3 where the slots allow it: same batches, every frame still uploaded once
     ctx = _FakeCtx(4, pipeline.min_frame_slots(4, 3), pipeline.min_flow_slots(4, 3))
-    assert pipeline.PairEngine(ctx).depth == 2                 # large (here: unknown) frame size: never more than 2 by default
-    ctx.width, ctx.height = 256, 256                           # small frames: 3 when the slots are there
-    eng = pipeline.PairEngine(ctx)
+    assert pipeline.PairEngine(ctx).depth == 2
+    eng = pipeline.PairEngine(ctx, depth=3)
     assert eng.depth == 3 and (ctx.frame_slots, ctx.flow_slots) == (20, 29)
     eng.pass1(frames, 0, 39)
     got = [p for b in ctx.batches for p in b]
