@@ -146,7 +146,7 @@ def _fit_chunk(width, height, n_pairs, device, max_batch, reclaim=0):
     budget = (free + reclaim) * 0.95 - reserve
     B = max_batch
     while True:
-        need, pinned = _capi.estimate_bytes(width, height, 2 * B + 2, max(n_pairs, 1), B)
+        need, pinned = _capi.estimate_bytes(width, height, 3 * (B + 1), max(n_pairs, 1), B)
         if need <= budget:
             return B, need
         if B == 1:
@@ -170,7 +170,8 @@ def _chunk_context(width, height, n_pairs, device, max_batch):
         if ctx is not None:
             ctx.close()
             _chunk_ctx.pop(key, None)
-        ctx = _capi.Context(width, height, device=device, frame_slots=2 * B + 2, flow_slots=max(n_pairs, 1), max_batch=B)
+        # frame slots: two batches queued ahead of the one being collected (pipeline.min_frame_slots(B, 2))
+        ctx = _capi.Context(width, height, device=device, frame_slots=3 * (B + 1), flow_slots=max(n_pairs, 1), max_batch=B)
         ctx._chunk_serial, ctx._asked_batch = serial, max_batch
         _chunk_ctx[key] = ctx
     ctx._chunk_serial += 1
@@ -183,9 +184,16 @@ class _ChunkFlow(DeviceFlow):
             raise _capi.FFLError("DeviceFlow handle is stale: a later precompute_all() call reused the chunk's flow slots")
 
 
+def default_batch(width, height):
+    """Pairs per device batch when params has no "hip_batch": the batch that fills the device at every pyramid level --
+    32 at 1920x1080 and above, growing as the frame shrinks, 256 (the API's limit) at 640x360 and below, i.e. at the
+    reference's own 256x256 operating point (FF:1057), where a 32-pair batch runs at 0.7x the rate of a 256-pair one."""
+    return int(min(_capi.FFL_MAX_BATCH, max(32, (32 * 1920 * 1080) // max(1, width * height))))
+
+
 def precompute_all(pairs, params):
     """Drop-in for `pool.starmap(precompute_wrapper, [(p, params) for p in pairs])` (FF:1190-1191): the same list of
-    result dicts (FF:898-907), computed in batches of params.get("hip_batch", 32) pairs with consecutive pairs
+    result dicts (FF:898-907), computed in batches of params.get("hip_batch", default_batch(w, h)) pairs with consecutive pairs
     sharing their frame (pairs = zip(frames[:-1], frames[1:]), FF:1188, is recognised by object identity); every
     flow field stays resident until the next precompute_all() call, like the reference's `precomputed`."""
     from . import pipeline
@@ -195,7 +203,7 @@ def precompute_all(pairs, params):
     if not pairs:
         return []
     h, w = pairs[0][0].shape[:2]
-    B = max(1, min(int(params.get("hip_batch", 32)), _capi.FFL_MAX_BATCH))
+    B = max(1, min(int(params.get("hip_batch", default_batch(w, h))), _capi.FFL_MAX_BATCH))
     ctx = _chunk_context(w, h, len(pairs), int(params.get("device", 0)), B)
     B = ctx.max_batch                       # possibly smaller than asked for: what fits beside the chunk's flows
     # frames of the chunk in order of first use; a pair's two operands become frame indices
@@ -214,6 +222,7 @@ def precompute_all(pairs, params):
     pov, thr = bool(params.get("pov_mode")), float(params.get("cut_threshold", 7))
     eng = pipeline.PairEngine.__new__(pipeline.PairEngine)   # slots are sized for the chunk here, not for a stream
     eng.ctx, eng.B, eng.upload = ctx, B, ctx.upload_frames
+    eng.depth = 2 if ctx.frame_slots >= pipeline.min_frame_slots(B, 2) else 1
     if stream:
         recs = eng.pass1_pairs(frames, range(len(pairs)), lambda l: l, pov, thr)
     else:  # arbitrary pairs: every pair brings its own two frames

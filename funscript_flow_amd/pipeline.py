@@ -18,19 +18,19 @@ SMOOTH_RADIUS = 6  # FF:1206 range(1, 7)
 
 
 def smooth_centers(pos_centers, radius=SMOOTH_RADIUS):
-    """FF:1203-1214: c_j = mean({p_i : |i-j| <= 6, 0 <= i < n}) as float64[2]."""
+    """FF:1203-1214: c_j = mean({p_i : |i-j| <= 6, 0 <= i < n}) as float64[2].
+
+    The reference gathers the window's positions into a list and takes np.mean(..., axis=0) of the int64 pairs: an exact
+    integer sum (far below 2^53) converted to float64 and divided by the count.  Window sums from a prefix sum give the
+    same integers, hence the same float64 -- bit for bit (pinned by the chain captured from the real process_video,
+    tests/test_host_side.py) -- without a Python loop over the chunk's 3000 pairs (13 ms -> 0.1 ms)."""
     p = np.asarray(pos_centers, np.int64).reshape(-1, 2)
     n = len(p)
-    out = np.empty((n, 2), np.float64)
-    for j in range(n):
-        idx = [j]
-        for i in range(1, radius + 1):
-            if j - i >= 0:
-                idx.append(j - i)
-            if j + i < n:
-                idx.append(j + i)
-        out[j] = np.mean(p[idx], axis=0)
-    return out
+    psum = np.zeros((n + 1, 2), np.int64)
+    np.cumsum(p, axis=0, out=psum[1:])
+    j = np.arange(n)
+    lo, hi = np.maximum(0, j - radius), np.minimum(n, j + radius + 1)
+    return (psum[hi] - psum[lo]) / (hi - lo)[:, None]
 
 
 def min_flow_slots(max_batch, depth=1):

@@ -92,6 +92,14 @@ def test_postchain_reproduces_reference_funscript(golden_dir):
     assert list(cum) == [0.0, 0.5, 1.5, 1.0, 2.5]
 
 
+def test_default_batch_follows_the_frame_size():
+    """backend.default_batch: the drop-in calls pick the pairs per device batch from the frame size when params has no
+    "hip_batch" -- 32 at 1080p and above, the API's 256 at the reference's own 256x256 operating point (FF:1057)."""
+    assert backend.default_batch(1920, 1080) == 32 and backend.default_batch(3840, 2160) == 32
+    assert backend.default_batch(256, 256) == 256 == _capi.FFL_MAX_BATCH and backend.default_batch(640, 360) == 256
+    assert backend.default_batch(1280, 720) == 72 and backend.default_batch(16, 16) == 256
+
+
 def test_shard_range_partitions():
     for n in (0, 1, 7, 8, 39, 1000):
         for world in (1, 2, 3, 8):
