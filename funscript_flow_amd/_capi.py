@@ -173,6 +173,24 @@ class Context:
 
     def upload_frames(self, first_slot, frames):
         """frames: sequence of equally shaped uint8 frames -> consecutive slots, one H2D transfer."""
+        f0 = frames[0]
+        shape, strides = f0.shape, f0.strides
+        if f0.dtype == np.uint8 and f0.ndim in (2, 3) and strides[-1] == 1 and (f0.ndim == 2 or strides[1] == shape[2]):
+            # the common case -- every frame an ndarray of frame 0's shape and strides -- in one pass: at 256x256 a batch is
+            # 257 frames, and what is done per frame in Python here is what the upload call costs the host
+            n = len(frames)
+            ptrs = np.empty(n, np.uintp)
+            uniform = True
+            for i, f in enumerate(frames):
+                if f.shape != shape or f.strides != strides or f.dtype != np.uint8:
+                    uniform = False          # the general path below converts or refuses it
+                    break
+                ptrs[i] = f.__array_interface__["data"][0]
+            if uniform:
+                ch = 1 if f0.ndim == 2 else shape[2]
+                self._chk(self.L.ffl_upload_frames(self._h, first_slot, n, ptrs.ctypes.data_as(C.POINTER(C.c_void_p)), shape[1], shape[0],
+                                                   ch, strides[0]))
+                return
         fr = [f if (f.strides[-1] == 1 and (f.ndim == 2 or f.strides[1] == f.shape[2])) else np.ascontiguousarray(f)
               for f in frames]
         f0 = fr[0]
