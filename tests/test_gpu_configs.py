@@ -626,3 +626,25 @@ def test_long_chunk_outlives_the_event_rings():
         assert (want_recs[j][0], want_recs[j][1]) == orc.max_divergence_np(flow)[:2], j
         ref = float(orc.radial_np(flow, centers[j], want_recs[j][4], False))
         assert abs(want_dots[j] - ref) <= 1e-4 * max(abs(ref), 1e-3), j
+
+
+def test_staged_upload_of_many_frames_with_a_row_stride_is_shared_by_the_copy_threads():
+    """ffl_upload_frames stages a run of frames with its rows split over the copy threads (CopyPool::copy), also when the
+    frames are views with a row stride (the right halves of wider arrays) and when a thread's share starts in the middle
+    of a frame: 37 frames of 300x200 (2.2 MB: above the 1 MiB threshold), 1 / 3 / 4 / 7 copy threads, gray and BGR."""
+    w, h, n = 300, 200, 37
+    rng = np.random.default_rng(5)
+    wide = rng.integers(0, 256, (n, h, 2 * w + 3), dtype=np.uint8)
+    views = [wide[i][:, w + 3:] for i in range(n)]                       # row stride 2w + 3, rows not contiguous
+    wide3 = rng.integers(0, 256, (n, h, w + 5, 3), dtype=np.uint8)
+    views3 = [wide3[i][:, 5:, :] for i in range(n)]
+    assert not views[0].flags["C_CONTIGUOUS"] and not views3[0].flags["C_CONTIGUOUS"]
+    for threads in (1, 3, 4, 7):
+        with _capi.Context(w, h, max_batch=4, frame_slots=n + 1, flow_slots=4) as ctx:
+            ctx.set_option("copy_threads", threads)
+            ctx.upload_frames(1, views)
+            for i in (0, 1, 17, 35, 36):
+                assert np.array_equal(ctx.download_frame(1 + i), views[i]), (threads, i)
+            ctx.upload_frames(0, views3)
+            for i in (0, 9, 36):
+                assert np.array_equal(ctx.download_frame(i), orc.bgr2gray(np.ascontiguousarray(views3[i]))), (threads, i)
