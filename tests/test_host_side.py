@@ -501,3 +501,36 @@ def test_process_wide_option_defaults_without_a_device():
     finally:
         _capi.set_option("lanes", 2)
         _capi.set_option("blur_min_wgs", 3500)
+
+
+def test_launcher_takes_its_ranks_down_when_it_is_terminated(tmp_path):
+    """A driver that gives up on `bench.py --gpus N` sends the PARENT a SIGTERM: the rank processes must not outlive it
+    (a rank left behind would keep a GPU and a rendezvous port busy for the next run)."""
+    import signal
+    import time
+    child = tmp_path / "sleeper.py"
+    child.write_text("import os, sys, time\nopen(sys.argv[1] + '.' + os.environ['RANK'], 'w').write(str(os.getpid()))\ntime.sleep(300)\n")
+    runner = tmp_path / "runner.py"
+    runner.write_text(f"import sys\nsys.path.insert(0, {ROOT!r})\nfrom funscript_flow_amd import launch\n"
+                      f"sys.exit(launch.spawn_ranks({str(child)!r}, [{str(tmp_path / 'pid')!r}], 3))\n")
+    p = subprocess.Popen([sys.executable, str(runner)])
+    try:
+        pids = []
+        deadline = time.monotonic() + 60
+        while len(pids) < 3 and time.monotonic() < deadline:
+            pids = [int(open(f).read()) for f in (str(tmp_path / f"pid.{r}") for r in range(3)) if os.path.exists(f) and open(f).read().strip()]
+            time.sleep(0.05)
+        assert len(pids) == 3
+        p.send_signal(signal.SIGTERM)
+        assert p.wait(timeout=30) == 128 + signal.SIGTERM
+        time.sleep(0.5)
+        for pid in pids:
+            try:
+                os.kill(pid, 0)
+                alive = open(f"/proc/{pid}/stat").read().split()[2] != "Z"      # a zombie of a dead parent is reaped by init
+            except (ProcessLookupError, FileNotFoundError):
+                alive = False
+            assert not alive, pid
+    finally:
+        if p.poll() is None:
+            p.kill()
