@@ -648,3 +648,22 @@ def test_staged_upload_of_many_frames_with_a_row_stride_is_shared_by_the_copy_th
             ctx.upload_frames(0, views3)
             for i in (0, 9, 36):
                 assert np.array_equal(ctx.download_frame(i), orc.bgr2gray(np.ascontiguousarray(views3[i]))), (threads, i)
+
+
+@pytest.mark.parametrize("assign", ["contiguous", "round_robin"])
+def test_bench_one_clip_is_checked_against_the_oracle_golden(assign):
+    """`bench.py --one-clip` (strong-scaling form; contiguous = the halo-only streaming exchange): its `checked` must come
+    from the oracle golden of the seed-1 stream (records of pairs 0..31, scalars of pairs 0..25), not only from the clip's
+    period-16 self-consistency (advisor, round 3)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--one-clip", "--assign", assign, "--steps", "2", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["mode"] == "one_clip" and line["scaling"] == "strong" and line["n_gpus"] == 1 and line["value"] > 0
+    if line["checked"] is None:
+        pytest.skip(line["check_detail"])
+    assert line["checked"] is True and "oracle golden" in line["check_detail"], line["check_detail"]
