@@ -1657,6 +1657,11 @@ __global__ __launch_bounds__(256, FIRST ? FFL_K5_WAVES_FIRST : FFL_K5_WAVES) voi
 // 2500 -3.0 %, 3000 +1.4, 3400-3840 +1.8, 4000 +0.6; 3840x2160 B = 32: 3000-3500 +2.8, 4000 +2.4, 6000 -0.1; 256x256
 // B = 256: 3000 -14.5 (a level lands on exactly 3072 workgroups), 3500-4000 +1.5, 6000 -2.2.
 static int ffl_blur_rows_per_wg(int tiles_x, int tiles_y, int nB, int min_wgs) {
+    // The threshold was tuned at B = 32.  On levels with many tiles per pair the strip length it gives there is also the best
+    // one for larger batches (1080p level 0: strips of 17 tiles at B = 32, 48, 64, 96 -- with the batch's own count the rule
+    // picks 23 / 34 tiles and the step loses 5 %, profiles/r04_strip_plain_and_batch_sweep.txt), so such levels count at most
+    // 32 pairs; small levels, where a large batch is what fills the device at all (256x256, B = 256), count the batch.
+    if (nB > 32 && tiles_x * tiles_y >= 256) nB = 32;
     for (int s = 1; s <= tiles_y; s++) {
         const int nrb = (tiles_y + s - 1) / s;
         if (nrb > 64) continue;
