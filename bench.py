@@ -272,14 +272,17 @@ def resident_pass(W, H, B, steps, warmup, device, seed, events, independent=Fals
     ctx.upload_frames(0, list(frames))
     ctx.sync()
     runner = StepRunner(ctx, B, independent, SMOOTH_RADIUS, depth)
+    # A generation-2 collection walks every object torch's import created (40-50 ms: longer than the whole
+    # timed region at small frame sizes); park those objects in the permanent generation first -- BEFORE the warm-up: a
+    # 50 ms pause between the warm-up and the timed region let the idle device drop its clocks, and the first timed
+    # steps then ran 1.5-2 % slow (k_blur_solve 346 us per launch over 20 timed steps against 340 over 100, whatever W).
+    gc.collect()
+    gc.freeze()
+    ctx.profile_enable(events)          # the warm-up steps are launched exactly as the timed ones
     if warmup > 0:
         runner.run(warmup)
     runner.results.clear()
-    ctx.profile_enable(events)
-    # A generation-2 collection walks every object torch's import created (40-50 ms: longer than the whole
-    # timed region at small frame sizes); park those objects in the permanent generation first.
-    gc.collect()
-    gc.freeze()
+    ctx.profile_read()                  # drops the warm-up's event records
     if barrier:
         barrier()
     t0 = time.perf_counter()
