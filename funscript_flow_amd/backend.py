@@ -223,17 +223,21 @@ def precompute_all(pairs, params):
     eng = pipeline.PairEngine.__new__(pipeline.PairEngine)   # slots are sized for the chunk here, not for a stream
     eng.ctx, eng.B, eng.upload = ctx, B, ctx.upload_frames
     eng.depth = 2 if ctx.frame_slots >= pipeline.min_frame_slots(B, 2) else 1
+    out = [None] * len(pairs)
+    serial = ctx._chunk_serial
+
+    def on_batch(ls, js, got):   # the dicts of a finished batch are built while the device runs the next ones
+        for l, (x, y, val, mean_mag, cut) in zip(ls, got):
+            pos_center = (np.int64(x), np.int64(y))
+            val_pos = 0 if pov else val                                   # FF:880-886
+            out[l] = {"flow": _ChunkFlow(ctx, l, serial), "pos_center": pos_center, "neg_center": pos_center,
+                      "val_pos": val_pos, "val_neg": val_pos, "cut": cut, "cut_center": pos_center[0], "mean_mag": mean_mag}
+
     if stream:
-        recs = eng.pass1_pairs(frames, range(len(pairs)), lambda l: l, pov, thr)
+        eng.pass1_pairs(frames, range(len(pairs)), lambda l: l, pov, thr, on_batch=on_batch)
     else:  # arbitrary pairs: every pair brings its own two frames
         flat = [f for p in pairs for f in p]
-        recs = eng.pass1_pairs(flat, range(0, 2 * len(pairs), 2), lambda l: l, pov, thr)
-    out = []
-    for l, (x, y, val, mean_mag, cut) in enumerate(recs):
-        pos_center = (np.int64(x), np.int64(y))
-        val_pos = 0 if pov else val                                   # FF:880-886
-        out.append({"flow": _ChunkFlow(ctx, l, ctx._chunk_serial), "pos_center": pos_center, "neg_center": pos_center,
-                    "val_pos": val_pos, "val_neg": val_pos, "cut": cut, "cut_center": pos_center[0], "mean_mag": mean_mag})
+        eng.pass1_pairs(flat, range(0, 2 * len(pairs), 2), lambda l: l, pov, thr, on_batch=on_batch)
     return out
 
 
